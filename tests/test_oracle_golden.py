@@ -1,0 +1,129 @@
+"""CPU: the oracle restatement (oracle/vit_oracle.py) against vectors produced by the
+reference itself (tests/golden/*.npz, written by tools/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_entry, entries
+from oracle import vit_oracle as vo
+from oracle.closed_form import closed_form_images, closed_form_state, exact_masks
+
+RT, AT = 2e-4, 1e-5   # fp32 round-off between two eager CPU formulations
+
+
+def load_case(golden_dir, tag):
+    fx = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads,
+                       init_values=float(fx["init_values"]))
+    params = closed_form_state(vo.param_shapes(cfg), gamma=cfg.init_values)
+    return fx, cfg, params, B, n_mask, steps
+
+
+@pytest.mark.parametrize("tag", ["t48", "t32"])
+def test_forward_modes(golden_dir, tag):
+    fx, cfg, p, B, n_mask, _ = load_case(golden_dir, tag)
+    x = closed_form_images(f"{tag}/0", B, cfg.img_size)
+    mask = torch.from_numpy(fx["mask0"])
+    assert torch.equal(mask, exact_masks(B, cfg.num_patches, n_mask, int(fx["mask_seed"])))
+    ends = vo.forward(p, cfg, x, None, True, "end")
+    fcs = vo.forward(p, cfg, x, None, True, "fc")
+    for i in range(cfg.depth):
+        check_entry(fx, f"fwd/end{i}", ends[i], RT, AT)
+        check_entry(fx, f"fwd/fc{i}", fcs[i], RT, AT)
+    check_entry(fx, "fwd/student_masked", vo.forward(p, cfg, x, mask, False), RT, AT)
+    check_entry(fx, "fwd/student_all", vo.forward(p, cfg, x, mask, True), RT, AT)
+
+
+@pytest.mark.parametrize("tag", ["t48", "t32"])
+def test_train_steps(golden_dir, tag):
+    fx, cfg, p, B, n_mask, steps = load_case(golden_dir, tag)
+    hp = vo.StepHParams(target_layers=tuple(int(v) for v in fx["target_layers"]))
+    ema = {k: v.clone() for k, v in p.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    for s in range(steps):
+        x = closed_form_images(f"{tag}/{s}", B, cfg.img_size)
+        mask = torch.from_numpy(fx[f"mask{s}"])
+        res = vo.train_step(p, ema, m, v, cfg, hp, x, mask, s + 1)
+        assert res.loss == pytest.approx(float(fx["step/loss"][s]), rel=2e-4)
+        assert res.grad_norm == pytest.approx(float(fx["step/grad_norm"][s]), rel=2e-3)
+        if s == 0:
+            names = entries(fx, "grad0")
+            assert set(names) == set(res.grads.keys())
+            for n in names:
+                check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
+    for n in entries(fx, "post"):
+        check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)
+    for n in entries(fx, "ema"):
+        check_entry(fx, "ema/" + n, ema[n], 1e-5, 1e-7)
+
+
+def test_param_groups(golden_dir):
+    fx, cfg, p, *_ = load_case(golden_dir, "t48")
+    nd = vo.no_decay_names(p)
+    assert nd == set(fx["groups/no_decay"].tolist())
+    assert set(p) - nd == set(fx["groups/decay"].tolist())
+
+
+def test_rel_pos_index_known_answer(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "vitb_spot.npz"))
+    assert np.array_equal(vo.relative_position_index(14), fx["rel_index_14"])
+
+
+def test_loss_curve_100_steps(golden_dir):
+    """north_star: loss curve within 1e-3 of the reference CPU path over 100 steps."""
+    fx = np.load(os.path.join(golden_dir, "loss_curve.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    p = closed_form_state(vo.param_shapes(cfg), gamma=0.1)
+    hp = vo.StepHParams(target_layers=(1,), lr=float(fx["lr"]))
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    fixed = [(closed_form_images(f"curve/{s}", B, img), torch.from_numpy(fx[f"mask{s}"])) for s in range(4)]
+    losses = []
+    for s in range(steps):
+        x, mask = fixed[s % 4]
+        losses.append(vo.train_step(p, ema, m, v, cfg, hp, x, mask, s + 1).loss)
+    np.testing.assert_allclose(np.array(losses), fx["loss"], atol=1e-3, rtol=0)
+
+
+def test_vitb_shape_spot(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "vitb_spot.npz"))
+    cfg = vo.VitConfig(init_values=0.1)
+    p = closed_form_state(vo.param_shapes(cfg), gamma=0.1)
+    x = closed_form_images("vitb", 2, 224)
+    mask = torch.from_numpy(fx["mask"])
+    ends = vo.forward(p, cfg, x, None, True, "end")
+    for i in range(12):
+        check_entry(fx, f"end{i}", ends[i], 5e-4, 5e-6)
+    leaves = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    stu = vo.forward(leaves, cfg, x, mask, False)
+    check_entry(fx, "student", stu, 5e-4, 5e-6)
+    loss = torch.nn.functional.smooth_l1_loss(stu, torch.zeros_like(stu), beta=2.0)
+    assert float(loss) == pytest.approx(float(fx["loss_vs_zero"]), rel=1e-4)
+    loss.backward()
+    for n in entries(fx, "grad"):
+        check_entry(fx, "grad/" + n, leaves[n].grad, 2e-3, 1e-8)
+
+
+def test_adamw_matches_torch_optim():
+    torch.manual_seed(0)
+    p = {"a.weight": torch.randn(5, 7), "a.bias": torch.randn(5)}
+    ref = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+    opt = torch.optim.AdamW([{"params": [ref["a.weight"]], "weight_decay": 0.05},
+                             {"params": [ref["a.bias"]], "weight_decay": 0.0}], lr=2e-3, eps=1e-8)
+    hp = vo.StepHParams()
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    for s in range(4):
+        g = {k: torch.randn_like(t) for k, t in p.items()}
+        for k in ref:
+            ref[k].grad = g[k].clone()
+        opt.step()
+        vo.adamw_step(p, g, m, v, s + 1, hp)
+    for k in p:
+        torch.testing.assert_close(p[k], ref[k].detach(), rtol=1e-5, atol=1e-7)

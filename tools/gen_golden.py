@@ -1,0 +1,199 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (imported from
+/root/reference through tools/ref_harness.py).  Build-container only; never runs on the GPU box.
+
+    python tools/gen_golden.py            # rewrites every fixture
+
+Fixtures are data only.  Weights and images come from oracle/closed_form.py (evaluated
+identically by the tests), so the files hold just masks and expected outputs: small tensors
+in full, large ones as (sum, abs-sum) + 64 evenly spaced samples.
+"""
+import argparse
+import os
+import sys
+from functools import partial
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ref_harness  # noqa: E402
+from oracle.closed_form import (checksum, closed_form_images, closed_form_state,  # noqa: E402
+                                exact_masks)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FULL_LIMIT = 4096   # tensors up to this many elements are stored in full
+
+
+def put(out, key, t):
+    t = t.detach()
+    if t.numel() <= FULL_LIMIT:
+        out[key + "/full"] = t.float().numpy()
+    else:
+        s, v = checksum(t)
+        out[key + "/sum"], out[key + "/samples"] = s, v
+
+
+def build(mc, img, dim, depth, heads, init_values):
+    model = mc.VisionTransformerForCyclicalTraining(
+        img_size=img, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4,
+        qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=init_values,
+        use_shared_rel_pos_bias=True, use_abs_pos_emb=False, drop_path_rate=0.0, attn_drop_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype == torch.float32}
+    model.load_state_dict(closed_form_state(shapes, gamma=init_values), strict=False)
+    return model
+
+
+def run_reference_steps(eng, model, batches, target_layers, lr=2e-3, wd=0.05, clip=3.0,
+                        l1_beta=2.0, decay=0.9998):
+    import optim_factory
+    import timm.utils as U
+    ema = U.ModelEmaV2(model, decay=decay)
+    args = SimpleNamespace(opt="adamw", lr=lr, weight_decay=wd, opt_eps=1e-8, opt_betas=(0.9, 0.999),
+                           momentum=0.9)
+    opt = optim_factory.create_optimizer(args, model)
+    names = {id(p): n for n, p in model.named_parameters()}
+    groups = {("decay" if g["weight_decay"] > 0 else "no_decay"): [names[id(p)] for p in g["params"]]
+              for g in opt.param_groups}
+    scaler = ref_harness.HarnessScaler()
+    rec = {"loss": [], "grad_norm": []}
+    first_grads = None
+    for s, (bx, bm) in enumerate(batches):
+        loader = [((bx, bm), torch.zeros(1))]
+        stats = eng.train_one_epoch(
+            model, ema, 0, decay, decay, target_layers, loader, opt, torch.device("cpu"), 0, scaler,
+            max_norm=clip, l1_beta=l1_beta, log_writer=None, lr_scheduler=None, start_steps=s,
+            lr_schedule_values=None, wd_schedule_values=None, l2_loss=False, layer_results="end",
+            var_w0=0.0, var_w1=0.0, start_lr_decay_at_step=-1, loss_scale=-1, mask_dropout_prob=-1.0,
+            target_layer_norm_last=True, target_batch_norm=False, target_instance_norm=False,
+            post_target_instance_norm=False, post_target_layer_norm=True, stochastic=False)
+        rec["loss"].append(stats["loss"])
+        rec["grad_norm"].append(float(stats["grad_norm"]))
+        if s == 0:
+            pn = [n for n, _ in model.named_parameters()]
+            first_grads = {n: g for n, g in zip(pn, scaler.grads) if g is not None}
+    return rec, first_grads, ema, groups
+
+
+def gen_model_case(mc, eng, tag, img, dim, depth, heads, init_values, B, n_mask, seed, steps=3):
+    model = build(mc, img, dim, depth, heads, init_values)
+    n_patches = (img // 16) ** 2
+    batches = [(closed_form_images(f"{tag}/{s}", B, img), exact_masks(B, n_patches, n_mask, seed + s))
+               for s in range(steps)]
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, steps], dtype=np.int64),
+           "init_values": np.float64(init_values), "mask_seed": np.int64(seed)}
+    x, mask = batches[0]
+    model.eval()
+    with torch.no_grad():
+        ends = model(x, None, True, layer_results="end")
+        fcs = model(x, None, True, layer_results="fc")
+        stu = model(x, mask, return_all_tokens=False)
+        stu_all = model(x, mask, return_all_tokens=True)
+    for i, (e, f) in enumerate(zip(ends, fcs)):
+        put(out, f"fwd/end{i}", e)
+        put(out, f"fwd/fc{i}", f)
+    put(out, "fwd/student_masked", stu)
+    put(out, "fwd/student_all", stu_all)
+    for s, (_, bm) in enumerate(batches):
+        out[f"mask{s}"] = bm.numpy()
+    model.train()
+    tl = list(range(depth // 2, depth))
+    rec, grads, ema, groups = run_reference_steps(eng, model, batches, tl)
+    out["target_layers"] = np.array(tl, dtype=np.int64)
+    out["step/loss"] = np.array(rec["loss"], dtype=np.float64)
+    out["step/grad_norm"] = np.array(rec["grad_norm"], dtype=np.float64)
+    for k, v in grads.items():
+        put(out, "grad0/" + k, v)
+    for k, v in model.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "post/" + k, v)
+    for k, v in ema.module.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "ema/" + k, v)
+    out["groups/decay"] = np.array(groups["decay"])
+    out["groups/no_decay"] = np.array(groups["no_decay"])
+    np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
+    print("wrote", tag, "loss", rec["loss"], "gnorm", rec["grad_norm"])
+
+
+CURVE_LR = 1e-4   # constant; the README recipe warms up from 1e-6, 2e-3 from step 0 is chaotic on a tiny model
+
+
+def gen_loss_curve(mc, eng):
+    img, dim, depth, heads, B, n_mask = 48, 128, 2, 2, 4, 5
+    model = build(mc, img, dim, depth, heads, 0.1)
+    fixed = [(closed_form_images(f"curve/{s}", B, img), exact_masks(B, 9, n_mask, 300 + s)) for s in range(4)]
+    batches = [fixed[s % 4] for s in range(100)]
+    model.train()
+    rec, _, _, _ = run_reference_steps(eng, model, batches, [1], lr=CURVE_LR)
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, 100], dtype=np.int64),
+           "loss": np.array(rec["loss"]), "grad_norm": np.array(rec["grad_norm"]), "lr": np.float64(CURVE_LR)}
+    for s, (_, bm) in enumerate(fixed):
+        out[f"mask{s}"] = bm.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss_curve.npz"), **out)
+    print("wrote loss curve", rec["loss"][:3], "...", rec["loss"][-3:])
+
+
+def gen_vitb_spot(mc):
+    """ViT-B shape, B=2, closed-form weights: per-layer checksums + samples, and gradients of
+    smooth_l1(student, 0) for blocks 0 and 11 and the non-block parameters."""
+    model = build(mc, 224, 768, 12, 12, 0.1)
+    B = 2
+    x = closed_form_images("vitb", B, 224)
+    mask = exact_masks(B, 196, 120, 11)
+    out = {"mask": mask.numpy()}
+    model.eval()
+    with torch.no_grad():
+        ends = model(x, None, True, layer_results="end")
+    for li, e in enumerate(ends):
+        put(out, f"end{li}", e)
+    stu = model(x, mask, return_all_tokens=False)
+    put(out, "student", stu)
+    loss = torch.nn.functional.smooth_l1_loss(stu, torch.zeros_like(stu), beta=2.0)
+    loss.backward()
+    out["loss_vs_zero"] = np.float64(loss.item())
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if n.startswith("blocks.") and not (n.startswith("blocks.0.") or n.startswith("blocks.11.")):
+            continue
+        put(out, f"grad/{n}", p.grad)
+    out["rel_index_14"] = model.rel_pos_bias.relative_position_index.numpy()
+    np.savez_compressed(os.path.join(OUT, "vitb_spot.npz"), **out)
+    print("wrote vitb spot; loss_vs_zero", loss.item())
+
+
+def gen_schedules():
+    import utils
+    out = {}
+    out["cos_a"] = utils.cosine_scheduler(2e-3, 1e-5, 4, 10, warmup_epochs=1, start_warmup_value=1e-6)
+    out["cos_b"] = utils.cosine_scheduler(0.05, 0.05, 3, 7)
+    out["cos_c"] = utils.cosine_scheduler(5e-4, 1e-6, 5, 9, warmup_epochs=2, start_warmup_value=1e-6, warmup_steps=4)
+    out["tri_a"] = utils.tri_phase_scheduler(2e-3, 1e-5, 5, 20, warmup_perc=0.05, decay_perc=0.15, start_warmup_value=1e-6)
+    out["tri_b"] = utils.tri_phase_scheduler(1e-3, 0.0, 2, 10, warmup_perc=0.0, decay_perc=0.5)
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+    print("wrote schedules")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    mc, eng = ref_harness.import_reference()
+    if a.only in (None, "model"):
+        gen_model_case(mc, eng, "t48", img=48, dim=128, depth=2, heads=2, init_values=0.1, B=3, n_mask=4, seed=1)
+        gen_model_case(mc, eng, "t32", img=32, dim=192, depth=3, heads=3, init_values=1e-4, B=2, n_mask=2, seed=2)
+    if a.only in (None, "curve"):
+        gen_loss_curve(mc, eng)
+    if a.only in (None, "vitb"):
+        gen_vitb_spot(mc)
+    if a.only in (None, "sched"):
+        gen_schedules()
+
+
+if __name__ == "__main__":
+    main()
