@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- pre-train images/sec of the data2vec ViT-B/16 step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full iteration of engine_for_cyclical.train_one_epoch on one synthetic batch that
+is already resident in HBM: teacher forward -> targets -> student forward (attn-drop 0.05,
+drop-path 0.25) -> SmoothL1 -> backward -> [gradient all-reduce] -> clip + AdamW -> EMA.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM
+gemm_nt_kernel, timed on its fc1 bias+GELU launches with HIP events on the launch stream);
+`cpu_baseline` times the oracle (the CPU restatement, kind "port") on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = 140.698        # student fwd + bwd + teacher fwd, algorithmic 2MNK
+PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    m = torch.zeros(B, 196, dtype=torch.int64)
+    for b in range(B):
+        m[b, torch.randperm(196, generator=g)[:120]] = 1          # exactly 120 masked patches
+    return x.to(device), m.view(B, 14, 14).to(device)
+
+
+def cpu_baseline(sample_bs=4, steps=2):
+    """Oracle (oracle/vit_oracle.py) timed on the host cores: same step, fp32, bounded sample."""
+    from oracle import vit_oracle as vo
+    cfg = vo.VitConfig(init_values=1e-4)
+    p = vo.init_params(cfg, seed=0)
+    e = {k: v.clone() for k, v in p.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    x, mask = synthetic_batch(sample_bs, 0, "cpu")
+    hp = vo.StepHParams()
+    vo.train_step(p, e, m, v, cfg, hp, x, mask, 1)               # warm-up
+    t0 = time.time()
+    for s in range(steps):
+        vo.train_step(p, e, m, v, cfg, hp, x, mask, s + 2)
+    dt = (time.time() - t0) / steps
+    return {"value": sample_bs / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (+1 warm-up) of the same ViT-B/16 step at bs={sample_bs}, fp32 eager PyTorch on host cores, dropout off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    from uncertainty_vit_amd import optim_factory, utils
+    from uncertainty_vit_amd.engine_for_cyclical import GradReducer, make_step_params, native_step
+    from uncertainty_vit_amd.modeling_cyclical import create_model
+    from uncertainty_vit_amd.native import check, cur_stream, lib
+
+    torch.manual_seed(0)           # identical initial weights on every rank (DDP broadcasts rank 0's)
+    model = create_model("beit_base_patch16_224", pretrained=False, drop_path_rate=0.25, drop_rate=0.0,
+                         use_shared_rel_pos_bias=True, use_abs_pos_emb=False, init_values=1e-4, attn_drop_rate=0.05,
+                         gp_layer=False, gumbel_softmax=False, sinkformer=False, h_sto_trans=False).to(dev)
+    model.train()
+    ema = utils.ModelEmaV2(model, decay=0.9998)
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
+    import builtins
+    _p = builtins.print
+    builtins.print = lambda *x, **k: None           # keep stdout to the single JSON line
+    opt = optim_factory.create_optimizer(A(), model)
+    builtins.print = _p
+    opt._ensure_state()
+    engine = model.engine(a.batch, teacher=ema.module, adam_m=opt.exp_avg, adam_v=opt.exp_avg_sq)
+    reducer = GradReducer(model, world > 1)
+    x, mask = synthetic_batch(a.batch, 1000 + rank, dev)
+    mask = mask.reshape(a.batch, -1).contiguous()
+    L = lib()
+
+    def step(i):
+        hp = make_step_params(list(range(6, 12)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, 0, i)
+        hp.lr = 2e-5       # warm-up-sized lr: random-init weights and fixed synthetic data, 2e-3 is the post-warm-up peak
+        native_step(engine, reducer, x, mask, hp)
+        opt.step_count += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    check(L.uvit_engine_profile(engine.h, 1, 4096), "profile on")
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
+    tot, n, fl = C.c_double(), C.c_int(), C.c_double()
+    check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
+    stats = torch.zeros(2).pin_memory()
+    check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.batch * world * a.steps / dt
+        kern_ms = tot.value / max(n.value, 1)
+        achieved = fl.value / (kern_ms * 1e-3) / 1e12 if n.value else 0.0
+        out = {
+            "metric": "pretrain images/sec (ViT-B/16 224, bs=128/GPU)", "value": round(value, 2), "unit": "img/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"beit_base_patch16_224 data2vec pretrain step, bs={a.batch}/GPU, 224x224 synthetic, "
+                                   "target_layers=[6..11], attn_drop 0.05, drop_path 0.25, clip 3.0, AdamW, EMA 0.9998",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "step_mfma_frac": round(value / world * GFLOP_PER_IMAGE * 1e9 / PEAK_BF16, 4),
+                       "final_loss": round(float(stats[0]), 5)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
+                         "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

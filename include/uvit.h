@@ -1,0 +1,192 @@
+/* libuvit -- C ABI of the MI355X-native data2vec ViT pre-training step.
+ *
+ * The reference (fx-erick/uncertainty-vit) is pure Python: it has no FFI / plugin boundary of
+ * its own.  This header is therefore the NEW native boundary the build
+ * defines; each entry point names the reference code it replaces.  Conventions:
+ *   - plain pointers and sizes, no torch types; every pointer is DEVICE memory unless noted;
+ *   - the caller allocates all buffers (arenas, workspace); nothing is allocated per call;
+ *   - every call is asynchronous and ordered on the `stream` argument (a hipStream_t);
+ *   - return value 0 = ok, negative = UVIT_ERR_*; nothing throws;
+ *   - no global state besides the engine object.
+ * Host-side mirror of the reference's Python API lives in uncertainty-vit_amd/ (ctypes).
+ */
+#ifndef UVIT_H
+#define UVIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVIT_VERSION 100
+#define UVIT_MAX_DEPTH 64
+
+typedef struct uvit_engine uvit_engine;
+typedef void* uvit_stream;   /* hipStream_t */
+
+/* Constructor arguments of VisionTransformerForCyclicalTraining (modeling_cyclical.py:34-60)
+ * plus the per-GPU batch the workspace is sized for. */
+typedef struct uvit_config {
+    int32_t img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden;
+    int32_t use_shared_rel_pos_bias;  /* modeling_cyclical.py:84-89 */
+    int32_t use_abs_pos_emb;          /* must be 0 (run_cyclical.py:55 default) */
+    int32_t batch;
+    float ln_eps;                     /* 1e-6, modeling_cyclical.py:294 */
+    float attn_drop_rate;             /* --attn_drop_rate */
+    float drop_path_rate;             /* --drop_path; per-layer linspace(0, rate, depth) */
+    int32_t bias_chunk;               /* batch elements summed in registers per rel-pos-bias slab (0 = default 8) */
+} uvit_config;
+
+/* One tensor of the flat parameter arena; `name` is the reference state-dict key. */
+typedef struct uvit_layout_entry {
+    char name[96];
+    int64_t offset;   /* in floats, multiple of 64 */
+    int64_t numel;
+    int32_t ndim;
+    int32_t decay;    /* 1 = weight-decay group (optim_factory.py:58-97) */
+    int64_t shape[4];
+} uvit_layout_entry;
+
+/* Buffers owned by the caller.  fp32 arenas hold `uvit_arena_numel` floats; bf16 shadows the
+ * same number of 2-byte elements.  Layout = [decay tensors | no-decay tensors]. */
+typedef struct uvit_buffers {
+    float* params;        /* student fp32 master weights */
+    float* grads;         /* student gradients */
+    float* adam_m;
+    float* adam_v;
+    float* ema;           /* EMA teacher fp32 (timm ModelEmaV2 at run_cyclical.py:503) */
+    void* params_bf16;    /* bf16 shadow of params (GEMM operands) */
+    void* params_bf16_t;  /* transposed bf16 copies of the 2-D Linear weights (dgrad operands) */
+    void* ema_bf16;       /* bf16 shadow of the teacher */
+    const int32_t* rel_index;  /* (N*N) relative_position_index as int32 (modeling_finetune.py:339-353) */
+    void* workspace;
+    int64_t workspace_bytes;
+} uvit_buffers;
+
+/* Per-step knobs of train_one_epoch (engine_for_cyclical.py:24-32, 47-56, 88-186). */
+typedef struct uvit_step_params {
+    int32_t target_layers[UVIT_MAX_DEPTH];
+    int32_t n_target_layers;
+    int32_t target_layer_norm_last;   /* not --no_target_layer_norm_last */
+    int32_t post_target_layer_norm;
+    int32_t l2_loss;
+    float l1_beta;
+    float loss_scale;                 /* -1 = off */
+    float clip_grad;                  /* <= 0: no clipping (norm still reported) */
+    float lr, weight_decay, beta1, beta2, eps;
+    int32_t opt_step;                 /* 1-based AdamW step count */
+    float ema_decay;                  /* cur_decay; EMA skipped when do_ema == 0 */
+    int32_t do_ema;
+    float grad_scale;                 /* multiplies gradients before clipping (1/world after a SUM all-reduce) */
+    uint32_t seed;                    /* dropout / drop-path stream */
+    uint32_t it;                      /* global iteration, decorrelates masks between steps */
+    int32_t train_dropout;            /* 1: apply attn_drop_rate and drop_path_rate in the student */
+} uvit_step_params;
+
+int uvit_version(void);
+
+/* ---- arena layout (single source of truth for the host-side state-dict views) ---- */
+int uvit_layout_count(const uvit_config* cfg);
+int uvit_layout_get(const uvit_config* cfg, int index, uvit_layout_entry* out);
+int64_t uvit_arena_numel(const uvit_config* cfg, int64_t* n_decay_out);
+int64_t uvit_workspace_bytes(const uvit_config* cfg);
+
+/* ---- engine ---- */
+uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_buffers* bufs, uvit_stream stream, int* err_out);
+void uvit_engine_destroy(uvit_engine* e);
+
+/* Refresh bf16 shadows (+ transposes) from the fp32 arenas: which = 1 student, 2 teacher, 3 both.
+ * Needed after load_state_dict / init (replaces nothing in the reference; precision plumbing). */
+int uvit_engine_sync_shadows(uvit_engine* e, int which, uvit_stream stream);
+
+/* VisionTransformerForCyclicalTraining.forward_features (modeling_cyclical.py:170-207) for
+ * `which` = 0 student / 1 teacher weights.  images (B,Cin,S,S) f32; mask (B,P) int64 or NULL.
+ * Leaves every layer's residual stream in the workspace (see uvit_engine_ws_ptr). Batch may be
+ * <= cfg.batch.  train_dropout applies attention dropout / drop-path with (seed, it). */
+int uvit_engine_forward_features(uvit_engine* e, int which, const float* images, const int64_t* mask, int batch,
+                                 int train_dropout, uint32_t seed, uint32_t it, uvit_stream stream);
+/* norm + drop cls + (masked-row gather) + lm_head (modeling_cyclical.py:207,215-225) on the last
+ * forward_features result.  all_tokens=1: out (B*P, C); else out (count, C) rows in mask order.
+ * out must hold B*P*C floats; *count_dev (device int) receives the number of valid rows. */
+int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float* out, int32_t* count_dev, uvit_stream stream);
+
+/* Device pointers into the workspace after a forward: name in {"x" (layer 0..depth residual stream
+ * (B,N,C) f32), "xm" (after the attention branch), "loss", "grad_norm", "targets", "outputs", "count"}. */
+void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer);
+
+/* ---- the training step, engine_for_cyclical.py:58-186 ---- */
+/* teacher forward (no grad) -> targets; student forward; loss; backward through lm_head + final norm */
+int uvit_step_begin(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
+                    uvit_stream stream);
+/* backward of block `layer` (call depth-1 .. 0); its gradients are complete afterwards */
+int uvit_step_backward_layer(uvit_engine* e, int layer, const uvit_step_params* hp, uvit_stream stream);
+/* token assembly + patch embedding + relative-position table gradients */
+int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream);
+/* clip_grad_norm_ + AdamW (utils.py:375-381) + EMA (engine_for_cyclical.py:182-185) + shadow refresh */
+int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream stream);
+/* all of the above on one stream (single-GPU fast path) */
+int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
+                    uvit_stream stream);
+/* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
+ * fused bias+GELU, gemm_nt_kernel<EPI_GELU>) with HIP events on the stream it runs on.
+ * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */
+int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
+int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
+/* copies {loss, grad_norm} to host memory; synchronises the stream */
+int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_stream stream);
+
+/* ---- individual operators (tests, autograd wrappers) ---- */
+typedef struct uvit_gemm_epilogue {
+    void* out; void* out2; const float* bias; const float* bias2; const float* gamma; const float* resid;
+    const float* rowscale; const void* aux; const int64_t* mask; const float* mask_token;
+    int32_t ldo, tokens, patches;
+} uvit_gemm_epilogue;
+enum { UVIT_EPI_BF16 = 0, UVIT_EPI_QKV = 1, UVIT_EPI_GELU = 2, UVIT_EPI_RESID = 3, UVIT_EPI_F32 = 4,
+       UVIT_EPI_PATCH = 5, UVIT_EPI_DGELU = 6 };
+
+/* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue: nn.Linear / F.linear sites of
+ * modeling_finetune.py:75-82,151,186 and the Conv2d-as-GEMM at :317 */
+int uvit_op_gemm_nt(int mode, const void* A_bf16, const void* W_bf16, int M, int N, int K, int lda, int ldw,
+                    const uvit_gemm_epilogue* epi, uvit_stream stream);
+/* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64 */
+int uvit_op_gemm_tn(const void* Y_bf16, const void* X_bf16, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
+                    uvit_stream stream);
+/* Attention core, modeling_finetune.py:152-185. qkv (B,N,3,H,64) bf16; biasP (H,NP,NP) f32 or NULL */
+int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
+                     float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
+int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+                     float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H, int N,
+                     int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
+int uvit_op_relpos_gather(const float* table, const int32_t* index, float* biasP, int H, int N, int NP, uvit_stream stream);
+int uvit_op_relpos_scatter(const float* slab, int nslab, const int32_t* index, float* dtable, int H, int N, int NP,
+                           uvit_stream stream);
+/* nn.LayerNorm forward / backward (modeling_finetune.py:290-299) */
+int uvit_op_ln_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* mean, float* rstd, int M, int C,
+                   float eps, uvit_stream stream);
+int uvit_op_ln_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* w,
+                   const float* dres, float* dx, float* dw, float* db, int M, int C, uvit_stream stream);
+/* ModelEmaV2._update with the lambda of engine_for_cyclical.py:183 */
+int uvit_op_ema(float* ema, const float* params, void* ema_bf16, int64_t n, float decay, uvit_stream stream);
+int uvit_op_sumsq(const float* g, int64_t n, double* out, uvit_stream stream);
+int uvit_op_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, int64_t n_decay, float lr,
+                  float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
+                  float grad_scale, float* gnorm_out, uvit_stream stream);
+/* F.smooth_l1_loss / F.mse_loss forward + gradient (engine_for_cyclical.py:147-150) */
+int uvit_op_smooth_l1(const float* out, const float* target, const int32_t* count_dev, float beta, int l2,
+                      float loss_scale, float* loss, void* dout_bf16, int Mmax, int C, uvit_stream stream);
+/* target builder, engine_for_cyclical.py:92-122 */
+int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
+                         int C, float eps, uvit_stream stream);
+int uvit_op_target_finalize(float* acc, const int32_t* count, int n_layers, int post_ln, int Mmax, int C, float eps,
+                            uvit_stream stream);
+int uvit_op_mask_compact(const int64_t* mask, int32_t* rowidx, int32_t* count, int B, int P, uvit_stream stream);
+int uvit_op_im2col(const float* img, void* cols_bf16, int B, int Cin, int img_size, int patch, uvit_stream stream);
+int uvit_op_droppath(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step,
+                     uvit_stream stream);
+int uvit_op_cast_bf16(const float* src, void* dst_bf16, int64_t n, uvit_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVIT_H */

@@ -2,7 +2,7 @@
 
 Closed-form pseudo-random tensors that the fixture generator (tools/gen_golden.py, which runs
 the reference) and the tests evaluate identically, so ViT-shaped weights and inputs never need
-to be committed: value[i] = scale * sin(i * a + b) with (a, b) derived from the tensor's name.
+to be committed: value[i] comes from an integer hash of i keyed by the tensor's name.
 """
 import hashlib
 
@@ -10,13 +10,26 @@ import numpy as np
 import torch
 
 
+def _mix32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
 def closed_form(name: str, shape, scale: float = 0.02) -> torch.Tensor:
-    h = int(hashlib.sha256(name.encode()).hexdigest()[:8], 16)
-    a = 0.37 + (h % 1000) / 1000.0
-    b = (h >> 10) % 628 / 100.0
+    """Uniform on [-scale*sqrt(3), scale*sqrt(3)] (std = scale) from an integer hash of the element
+    index keyed by the tensor name: bit-reproducible on any host (integer arithmetic only)."""
+    key = np.uint32(int(hashlib.sha256(name.encode()).hexdigest()[:8], 16))
     n = int(np.prod(shape))
-    i = torch.arange(n, dtype=torch.float64)
-    return (scale * torch.sin(i * a + b)).float().reshape(tuple(shape))
+    with np.errstate(over="ignore"):
+        h = _mix32(_mix32(np.arange(n, dtype=np.uint32) ^ key) + np.uint32(0x9E3779B9))
+    u = (h.astype(np.float64) + 0.5) / 4294967296.0
+    v = (scale * np.sqrt(3.0) * (2.0 * u - 1.0)).astype(np.float32)
+    return torch.from_numpy(v).reshape(tuple(shape))
 
 
 def closed_form_state(shapes: dict, table_scale: float = 0.05, gamma: float = 0.1) -> dict:
@@ -36,7 +49,7 @@ def closed_form_state(shapes: dict, table_scale: float = 0.05, gamma: float = 0.
     return out
 
 
-def closed_form_images(tag: str, B: int, img: int, scale: float = 1.5) -> torch.Tensor:
+def closed_form_images(tag: str, B: int, img: int, scale: float = 1.0) -> torch.Tensor:
     return closed_form("images/" + tag, (B, 3, img, img), scale)
 
 

@@ -1,0 +1,348 @@
+"""GPU parity of each HIP operator, called through the C ABI, against a plain PyTorch fp32
+restatement of the same reference arithmetic on the same seeded inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from uncertainty_vit_amd import native
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return native.lib()
+
+
+def P(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ok(rc):
+    assert rc == 0, f"libuvit returned {rc}"
+
+
+def bf(t):
+    return t.to(torch.bfloat16).contiguous()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def epi(**kw):
+    from uncertainty_vit_amd.native import GemmEpilogue
+    e = GemmEpilogue()
+    for k, v in kw.items():
+        setattr(e, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return e
+
+
+# bf16 inputs, fp32 accumulate: error budget for a K-long dot of O(1) terms
+def close(a, b, rtol=2e-2, atol=2e-2, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} off, max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 192, 128), (1000, 768, 768), (394, 2304, 192), (64, 3072, 768)])
+def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_gemm_nt(0, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, bias=b, ldo=N)), S()))
+    close(out, ref, what="bf16 out")
+    out32 = torch.zeros(M, N, device="cuda")
+    ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+    close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
+
+
+def test_gemm_nt_asymmetric_identity(L):
+    """A = I with an asymmetric W catches a transposed C write (guide section 3)."""
+    K = 128
+    a = bf(torch.eye(K).cuda())
+    w = bf((torch.arange(192 * K).reshape(192, K) % 251 - 125).float().cuda() / 64)
+    out = torch.zeros(K, 192, device="cuda")
+    ok(L.uvit_op_gemm_nt(4, P(a), P(w), K, 192, K, K, K, C.byref(epi(out=out, ldo=192)), S()))
+    torch.testing.assert_close(out, w.float().t().contiguous(), rtol=0, atol=0)
+
+
+def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L):
+    M, Cd, Hd, tokens = 3 * 10, 128, 512, 10
+    x = bf(rnd(M, Cd, seed=4))
+    # QKV: bias = cat(q_bias, 0, v_bias)
+    w = bf(rnd(3 * Cd, Cd, scale=0.05, seed=5)); qb, vb = rnd(Cd, seed=6), rnd(Cd, seed=7)
+    out = torch.zeros(M, 3 * Cd, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_gemm_nt(1, P(x), P(w), M, 3 * Cd, Cd, Cd, Cd, C.byref(epi(out=out, bias=qb, bias2=vb, ldo=3 * Cd)), S()))
+    close(out, x.float() @ w.float().t() + torch.cat([qb, torch.zeros_like(vb), vb]), what="qkv")
+    # GELU: a = gelu(h), h kept
+    w1 = bf(rnd(Hd, Cd, scale=0.1, seed=8)); b1 = rnd(Hd, seed=9)
+    a_out = torch.zeros(M, Hd, dtype=torch.bfloat16, device="cuda"); h_out = torch.zeros_like(a_out)
+    ok(L.uvit_op_gemm_nt(2, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a_out, out2=h_out, bias=b1, ldo=Hd)), S()))
+    h_ref = x.float() @ w1.float().t() + b1
+    close(h_out, h_ref, what="gelu h")
+    close(a_out, F.gelu(h_out.float()), rtol=1e-2, atol=1e-2, what="gelu a")
+    # RESID: x + dp * gamma * (a @ W2^T + b2)
+    w2 = bf(rnd(Cd, Hd, scale=0.05, seed=10)); b2, gam = rnd(Cd, seed=11), rnd(Cd, scale=0.1, seed=12)
+    res = rnd(M, Cd, seed=13); dp = torch.tensor([0.0, 1.25, 1.25], device="cuda")
+    xo = torch.zeros(M, Cd, device="cuda"); branch = torch.zeros(M, Cd, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_gemm_nt(3, P(a_out), P(w2), M, Cd, Hd, Hd, Hd,
+                         C.byref(epi(out=xo, out2=branch, bias=b2, gamma=gam, resid=res, rowscale=dp, ldo=Cd, tokens=tokens)), S()))
+    y = a_out.float() @ w2.float().t() + b2
+    close(branch, y, what="resid branch")
+    close(xo, res + dp.repeat_interleave(tokens)[:, None] * gam * y, rtol=5e-3, atol=5e-3, what="resid out")
+    # DGELU: dH = (dY @ W2) * gelu'(h)
+    dy = bf(rnd(M, Cd, scale=0.1, seed=14)); w2t = bf(w2.float().t())
+    dh = torch.zeros(M, Hd, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_gemm_nt(6, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh, aux=h_out, ldo=Hd)), S()))
+    hh = h_out.float().requires_grad_(True)
+    F.gelu(hh).backward(dy.float() @ w2.float())
+    close(dh, hh.grad, rtol=2e-2, atol=5e-3, what="dgelu")
+    # PATCH: rows b*P+p -> token rows b*(P+1)+1+p, masked rows take the mask token
+    B, Pn, Kpe = 3, 9, 768
+    cols = bf(rnd(B * Pn, Kpe, seed=15)); wpe = bf(rnd(Cd, Kpe, scale=0.03, seed=16)); bpe = rnd(Cd, seed=17)
+    mt = rnd(Cd, seed=18); mask = (torch.arange(B * Pn, device="cuda") % 3 == 0).long()
+    x0 = torch.full((B * (Pn + 1), Cd), 7.0, device="cuda")
+    ok(L.uvit_op_gemm_nt(5, P(cols), P(wpe), B * Pn, Cd, Kpe, Kpe, Kpe,
+                         C.byref(epi(out=x0, bias=bpe, mask=mask, mask_token=mt, ldo=Cd, patches=Pn)), S()))
+    ref = cols.float() @ wpe.float().t() + bpe
+    ref = torch.where(mask[:, None].bool(), mt[None, :].expand_as(ref), ref).view(B, Pn, Cd)
+    got = x0.view(B, Pn + 1, Cd)
+    close(got[:, 1:], ref, rtol=5e-3, atol=5e-3, what="patch")
+    assert torch.all(got[:, 0] == 7.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (128, 192, 576), (25216, 768, 768), (1024, 3072, 768)])
+def test_gemm_tn_wgrad(L, M, N, K):
+    y, x = bf(rnd(M, N, scale=0.1, seed=20)), bf(rnd(M, K, seed=21))
+    out = torch.zeros(N, K, device="cuda")
+    ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+    ref = y.float().t() @ x.float()
+    close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M / 64), what="wgrad")
+
+
+def test_gemm_tn_asymmetric(L):
+    M, N, K = 64, 128, 192
+    y = torch.zeros(M, N, device="cuda"); y[torch.arange(M), torch.arange(M)] = 1.0     # Y^T picks rows of X
+    x = ((torch.arange(M * K).reshape(M, K) % 127) - 63).float().cuda() / 32
+    out = torch.zeros(N, K, device="cuda")
+    yb, xb = bf(y), bf(x)          # keep the operands alive across the asynchronous launch
+    ok(L.uvit_op_gemm_tn(P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
+    ref = torch.zeros(N, K, device="cuda"); ref[:M] = xb.float()
+    torch.testing.assert_close(out, ref, rtol=0, atol=0)
+
+
+def attn_ref(qkv, bias, B, H, N, keep=None):
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-2, -1)
+    if bias is not None:
+        s = s + bias
+    a = s.softmax(-1)
+    lse = torch.logsumexp(s, -1)
+    if keep is not None:
+        a = a * keep
+    return (a @ v).transpose(1, 2).reshape(B, N, H * 64), lse
+
+
+def padded_bias(bias, NP=208):
+    H, N, _ = bias.shape
+    bp = torch.zeros(H, NP, NP, device="cuda")
+    bp[:, :N, :N] = bias
+    return bp
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 2, 10), (1, 3, 5), (2, 12, 197), (3, 2, 64)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_fwd_bwd(L, B, H, N, p_drop):
+    from oracle.vit_oracle import attn_keep_mask
+    Cd = H * 64
+    qkv = bf(rnd(B * N, 3 * Cd, seed=30)).requires_grad_(False)
+    bias = rnd(H, N, N, scale=0.5, seed=31)
+    biasP = padded_bias(bias)
+    seed, layer = 1234, 3
+    keep = attn_keep_mask(seed, layer, B, H, N, p_drop).cuda() if p_drop > 0 else None
+    out = torch.zeros(B * N, Cd, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, N, device="cuda")
+    ok(L.uvit_op_attn_fwd(P(qkv), P(biasP), P(out), P(lse), B, H, N, 208, C.c_float(0.125), C.c_float(p_drop), seed, layer, S()))
+    qf = qkv.float().requires_grad_(True)
+    bq = bias.clone().requires_grad_(True)
+    ref, lse_ref = attn_ref(qf, bq, B, H, N, keep)
+    close(out.view(B, N, Cd), ref, rtol=2e-2, atol=1e-2, what="attn out")
+    close(lse, lse_ref, rtol=1e-3, atol=2e-3, what="lse")
+    # backward
+    d_o = bf(rnd(B * N, Cd, scale=0.5, seed=32))
+    ref.backward(d_o.float().view(B, N, Cd))
+    delta = torch.zeros(B, H, N, device="cuda")
+    dqkv = torch.zeros(B * N, 3 * Cd, dtype=torch.bfloat16, device="cuda")
+    chunk = 2
+    nchunk = (B + chunk - 1) // chunk
+    slab = torch.zeros(nchunk, H, 208, 208, device="cuda")
+    ok(L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab), 0, chunk, B, H, N, 208,
+                          C.c_float(0.125), C.c_float(p_drop), seed, layer, S()))
+    g = qf.grad
+    scale = g.abs().max().item()
+    close(dqkv, g, rtol=3e-2, atol=2e-2 * scale, what="dqkv")
+    dbias = slab.sum(0)[:, :N, :N].transpose(1, 2)      # slab is [h][key][q]
+    close(dbias, bq.grad, rtol=3e-2, atol=2e-2 * bq.grad.abs().max().item(), what="dbias")
+    # accumulate flag adds on top
+    ok(L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab), 1, chunk, B, H, N, 208,
+                          C.c_float(0.125), C.c_float(p_drop), seed, layer, S()))
+    close(slab.sum(0)[:, :N, :N].transpose(1, 2), 2 * bq.grad, rtol=3e-2, atol=4e-2 * bq.grad.abs().max().item(), what="dbias x2")
+
+
+def test_attention_dropout_rate_and_determinism(L):
+    B, H, N = 4, 12, 197
+    qkv = bf(rnd(B * N, 3 * H * 64, seed=33))
+    out1 = torch.zeros(B * N, H * 64, dtype=torch.bfloat16, device="cuda"); out2 = torch.zeros_like(out1)
+    lse = torch.zeros(B, H, N, device="cuda")
+    for o in (out1, out2):
+        ok(L.uvit_op_attn_fwd(P(qkv), P(None), P(o), P(lse), B, H, N, 208, C.c_float(0.125), C.c_float(0.05), 7, 1, S()))
+    assert torch.equal(out1, out2)
+    from oracle.vit_oracle import attn_keep_mask
+    keep = attn_keep_mask(7, 1, B, H, N, 0.05)
+    assert abs((keep == 0).float().mean().item() - 0.05) < 2e-3
+
+
+def test_relpos_gather_scatter(L):
+    from uncertainty_vit_amd.modeling_cyclical import relative_position_index
+    H, ws = 3, 3
+    N = ws * ws + 1
+    idx = relative_position_index(ws).cuda()
+    table = rnd((2 * ws - 1) ** 2 + 3, H, seed=40)
+    biasP = torch.full((H, 208, 208), 9.0, device="cuda")
+    i32 = idx.to(torch.int32).contiguous()
+    ok(L.uvit_op_relpos_gather(P(table), P(i32), P(biasP), H, N, 208, S()))
+    ref = table[idx.view(-1)].view(N, N, H).permute(2, 0, 1)
+    torch.testing.assert_close(biasP[:, :N, :N], ref)
+    assert biasP[:, N:, :].abs().sum() == 0 and biasP[:, :, N:].abs().sum() == 0
+    slab = torch.zeros(2, H, 208, 208, device="cuda")
+    dS = rnd(2, H, N, N, seed=41)                       # [slab][h][q][k]
+    slab[:, :, :N, :N] = dS.transpose(2, 3)             # stored [key][q]
+    dt = torch.zeros_like(table)
+    ok(L.uvit_op_relpos_scatter(P(slab), 2, P(i32), P(dt), H, N, 208, S()))
+    ref = torch.zeros_like(table)
+    ref.index_add_(0, idx.view(-1), dS.sum(0).permute(1, 2, 0).reshape(N * N, H))
+    torch.testing.assert_close(dt, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,Cd", [(30, 128), (10, 192), (1000, 768), (77, 1024)])
+def test_layernorm_fwd_bwd(L, M, Cd):
+    x = rnd(M, Cd, seed=50) * 2 + 0.3
+    w, b = rnd(Cd, seed=51) * 0.2 + 1, rnd(Cd, seed=52) * 0.1
+    y = torch.zeros(M, Cd, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+    ok(L.uvit_op_ln_fwd(P(x), P(w), P(b), P(y), P(mean), P(rstd), M, Cd, C.c_float(1e-6), S()))
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (Cd,), wr, br, 1e-6)
+    close(y, ref, rtol=1e-2, atol=1e-2, what="ln fwd")
+    torch.testing.assert_close(mean, x.mean(-1), rtol=1e-5, atol=1e-5)
+    dy = bf(rnd(M, Cd, seed=53)); dres = rnd(M, Cd, seed=54)
+    ref.backward(dy.float())
+    dx = torch.zeros(M, Cd, device="cuda"); dw = torch.zeros(Cd, device="cuda"); db = torch.zeros(Cd, device="cuda")
+    ok(L.uvit_op_ln_bwd(P(dy), P(x), P(mean), P(rstd), P(w), P(dres), P(dx), P(dw), P(db), M, Cd, S()))
+    torch.testing.assert_close(dx, xr.grad + dres, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dw, wr.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_ema_adamw_sumsq_against_torch(L):
+    n, n_decay = 64 * 1000, 64 * 600
+    p = rnd(n, seed=60); g = rnd(n, seed=61) * 3
+    e = rnd(n, seed=62)
+    e0, p0 = e.clone(), p.clone()
+    eb = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_ema(P(e), P(p), P(eb), n, C.c_float(0.9998), S()))
+    torch.testing.assert_close(e, 0.9998 * e0 + (1 - 0.9998) * p0, rtol=1e-6, atol=1e-7)   # engine_for_cyclical.py:183
+    assert torch.equal(eb, e.to(torch.bfloat16))
+    ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ok(L.uvit_op_sumsq(P(g), n, P(ss), S()))
+    assert abs(ss.item() - (g.double() ** 2).sum().item()) < 1e-6 * ss.item()
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [ref], "weight_decay": 0.0}], lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    pb = torch.zeros(n, dtype=torch.bfloat16, device="cuda"); gn = torch.zeros(1, device="cuda")
+    refd = p0[:n_decay].clone().requires_grad_(True); refn = p0[n_decay:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [refd], "weight_decay": 0.05}, {"params": [refn], "weight_decay": 0.0}],
+                            lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(1, 4):
+        gg = g * step
+        refd.grad, refn.grad = gg[:n_decay].clone(), gg[n_decay:].clone()
+        norm = torch.nn.utils.clip_grad_norm_([refd, refn], 3.0)
+        opt.step()
+        ss.zero_()
+        ok(L.uvit_op_sumsq(P(gg), n, P(ss), S()))
+        ok(L.uvit_op_adamw(P(p), P(gg), P(m), P(v), P(pb), n, n_decay, C.c_float(2e-3), C.c_float(0.05), C.c_float(0.9),
+                           C.c_float(0.999), C.c_float(1e-8), step, P(ss), C.c_float(3.0), C.c_float(1.0), P(gn), S()))
+        assert abs(gn.item() - norm.item()) < 1e-4 * norm.item()
+    torch.testing.assert_close(p, torch.cat([refd, refn]).detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("beta,l2", [(2.0, 0), (0.12, 0), (1.0, 1)])
+def test_smooth_l1_fwd_bwd(L, beta, l2):
+    Mmax, Cd, cnt = 64, 128, 50
+    out = rnd(Mmax, Cd, seed=70) * 3; tgt = rnd(Mmax, Cd, seed=71)
+    count = torch.tensor([cnt], dtype=torch.int32, device="cuda")
+    loss = torch.zeros(1, device="cuda"); dout = torch.ones(Mmax, Cd, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_smooth_l1(P(out), P(tgt), P(count), C.c_float(beta), l2, C.c_float(1.0), P(loss), P(dout), Mmax, Cd, S()))
+    o = out[:cnt].clone().requires_grad_(True)
+    ref = F.mse_loss(o, tgt[:cnt]) if l2 else F.smooth_l1_loss(o, tgt[:cnt], beta=beta)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-7
+    close(dout[:cnt], o.grad, rtol=1e-2, atol=1e-7, what="dout")
+    assert dout[cnt:].abs().sum() == 0
+
+
+def test_mask_compact_im2col_targets_droppath(L):
+    from oracle import vit_oracle as vo
+    B, g = 5, 14
+    Pn = g * g
+    mask = (torch.rand(B, Pn, generator=torch.Generator().manual_seed(80)) < 0.6).long().cuda()
+    rowidx = torch.full((B * Pn,), -1, dtype=torch.int32, device="cuda"); count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ok(L.uvit_op_mask_compact(P(mask), P(rowidx), P(count), B, Pn, S()))
+    nz = mask.view(-1).nonzero().view(-1)
+    ref_rows = (nz // Pn) * (Pn + 1) + 1 + nz % Pn
+    assert count.item() == nz.numel()
+    assert torch.equal(rowidx[: nz.numel()].long(), ref_rows)
+    # empty and full masks
+    for m in (torch.zeros_like(mask), torch.ones_like(mask)):
+        ok(L.uvit_op_mask_compact(P(m), P(rowidx), P(count), B, Pn, S()))
+        assert count.item() == int(m.sum())
+    # im2col == conv patches
+    img = rnd(2, 3, 48, 48, seed=81)
+    cols = torch.zeros(2 * 9, 768, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_im2col(P(img), P(cols), 2, 3, 48, 16, S()))
+    ref = img.reshape(2, 3, 3, 16, 3, 16).permute(0, 2, 4, 1, 3, 5).reshape(18, 768)
+    assert torch.equal(cols, ref.to(torch.bfloat16))
+    # target builder on masked rows: LN(no affine, 1e-5) per layer, mean, post LN
+    ok(L.uvit_op_mask_compact(P(mask), P(rowidx), P(count), B, Pn, S()))
+    Cd = 128
+    layers = [rnd(B * (Pn + 1), Cd, seed=82 + i) * (i + 1) for i in range(3)]
+    acc = torch.zeros(B * Pn, Cd, device="cuda")
+    for i, x in enumerate(layers):
+        ok(L.uvit_op_target_accum(P(x), P(rowidx), P(count), P(acc), 1 if i == 0 else 0, B * Pn, Cd, C.c_float(1e-5), S()))
+    ok(L.uvit_op_target_finalize(P(acc), P(count), 3, 1, B * Pn, Cd, C.c_float(1e-5), S()))
+    hp = vo.StepHParams(target_layers=(0, 1, 2))
+    ref = vo.build_targets([x.view(B, Pn + 1, Cd)[:, 1:].cpu() for x in layers], mask.view(B, g, g).cpu(), hp)
+    torch.testing.assert_close(acc[: ref.shape[0]].cpu(), ref, rtol=1e-4, atol=1e-4)
+    # drop-path multipliers mirror the oracle's counter-based stream
+    cfg = vo.VitConfig(depth=4, drop_path_rate=0.25)
+    rates = torch.tensor(cfg.drop_path_rates(), device="cuda")
+    sc = torch.zeros(4 * 2 * 7, device="cuda")
+    ok(L.uvit_op_droppath(P(sc), P(rates), 4, 7, 99, 5, S()))
+    p1, p2 = vo.drop_path_scales(99, 5, cfg, 7)
+    sc = sc.view(4, 2, 7).cpu()
+    for i in range(4):
+        for br, ref in ((0, p1[i]), (1, p2[i])):
+            torch.testing.assert_close(sc[i, br], torch.ones(7) if ref is None else ref, rtol=1e-6, atol=0)

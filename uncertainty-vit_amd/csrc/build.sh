@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build libuvit.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=${1:-../libuvit.so}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wall -Wno-unused-function"
+mkdir -p obj
+pids=()
+for f in gemm attention norm elementwise optim engine; do
+  ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" obj/*.o
+echo "built $OUT"

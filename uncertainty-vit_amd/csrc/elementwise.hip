@@ -1,0 +1,353 @@
+// HBM-bound helper kernels of the ViT step (gfx950): patch re-indexing, token assembly and its
+// backward, mask compaction, relative-position bias gather / gradient scatter, LayerScale
+// backward, column sums (bias gradients), the fused SmoothL1 loss forward+backward, batched
+// weight transposes and the drop-path multipliers.
+#include "common.h"
+#include "uvit_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// images (B,Cin,S,S) f32 -> cols (B*P, Cin*p*p) bf16, k = c*p*p + i*p + j   (conv == GEMM,
+// modeling_finetune.py:317-325).  One thread moves 8 pixels of one patch row.
+// ------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int B, int Cin, int S, int p) {
+    const int g = S / p, P = g * g, K = Cin * p * p, kc_per_row = K / 8;
+    const size_t total = (size_t)B * P * kc_per_row;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kc = idx % kc_per_row;
+        const size_t row = idx / kc_per_row;
+        const int b = row / P, pp = row % P, py = pp / g, px = pp % g;
+        const int k = kc * 8, c = k / (p * p), i = (k % (p * p)) / p, j = k % p;
+        const float* src = img + (((size_t)b * Cin + c) * S + py * p + i) * S + px * p + j;
+        const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+        bf16x8 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w), f2bf(d.x), f2bf(d.y), f2bf(d.z), f2bf(d.w)};
+        *(bf16x8*)(cols + row * K + k) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mask (B*P int64 0/1) -> ordered list of masked token rows b*(P+1)+1+p and their count.
+// Single workgroup; 25k elements.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024)
+void mask_compact_kernel(const int64_t* __restrict__ mask, int* __restrict__ rowidx, int* __restrict__ count, int B, int P) {
+    __shared__ int part[1024];
+    const int n = B * P, tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += mask[i] != 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {     // inclusive Hillis-Steele scan
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - c;
+    for (int i = lo; i < hi; ++i)
+        if (mask[i] != 0) { const int b = i / P; rowidx[pos++] = b * (P + 1) + 1 + (i - b * P); }
+    if (tid == 1023) *count = part[1023];
+    // unused tail entries point at a valid row so gathers stay in bounds
+    for (int i = part[1023] + tid; i < n; i += 1024) rowidx[i] = 0;
+}
+
+__global__ void set_cls_kernel(float* __restrict__ x, const float* __restrict__ cls, int B, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * C) { const int b = i / C, c = i - b * C; x[(size_t)b * N * C + c] = cls[c]; }
+}
+
+// biasP[h][q][k] = table[index[q*N+k]][h]; padded to NP x NP with zeros (modeling_finetune.py:359-364)
+__global__ void relpos_gather_kernel(const float* __restrict__ table, const int* __restrict__ index,
+                                     float* __restrict__ biasP, int H, int N, int NP) {
+    const size_t total = (size_t)H * NP * NP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = i % NP, q = (i / NP) % NP, h = i / ((size_t)NP * NP);
+        biasP[i] = (q < N && k < N) ? table[(size_t)index[q * N + k] * H + h] : 0.f;
+    }
+}
+
+// dtable[index[q*N+k]][h] += sum_slabs slab[s][h][k][q]   (slabs hold dS^T summed over batch chunks and layers)
+__global__ void relpos_scatter_kernel(const float* __restrict__ slab, int nslab, const int* __restrict__ index,
+                                      float* __restrict__ dtable, int H, int N, int NP, int ntable) {
+    extern __shared__ float tsum[];
+    const int h = blockIdx.x;
+    for (int i = threadIdx.x; i < ntable; i += blockDim.x) tsum[i] = 0.f;
+    __syncthreads();
+    const int total = N * N;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += gridDim.y * blockDim.x) {
+        const int k = i / N, q = i - k * N;
+        float s = 0.f;
+        for (int sl = 0; sl < nslab; ++sl) s += slab[(((size_t)sl * H + h) * NP + k) * NP + q];
+        atomicAdd(&tsum[index[q * N + k]], s);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntable; i += blockDim.x)
+        if (tsum[i] != 0.f) atomicAdd(dtable + (size_t)i * H + h, tsum[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// column-partial machinery: 4 waves x 64 lanes, each lane owns float4 column groups
+// ------------------------------------------------------------------------------------------
+#define CP_MAXV 8
+#define CP_ROWS 32
+
+__device__ __forceinline__ void block_col_atomic(float4 (&acc)[CP_MAXV], float* out, int nv, float (*red)[64 * 4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < CP_MAXV; ++k) {
+        if (64 * k < nv) {
+            __syncthreads();
+            ((float4*)red[wave])[lane] = acc[k];
+            __syncthreads();
+            if (wave == 0) {
+                float4 s = ((float4*)red[0])[lane];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) { const float4 a = ((float4*)red[q])[lane]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+                const int i = lane + 64 * k;
+                if (i < nv) { atomicAdd(out + 4 * i, s.x); atomicAdd(out + 4 * i + 1, s.y); atomicAdd(out + 4 * i + 2, s.z); atomicAdd(out + 4 * i + 3, s.w); }
+            }
+        }
+    }
+}
+
+// LayerScale + DropPath backward (modeling_finetune.py:295-298):
+//   dy = dx * gamma * dp[b]   (bf16, gradient of the Linear output y)
+//   dgamma += sum_m dx * dp * y ;  dbias += sum_m dy
+__global__ __launch_bounds__(256)
+void ls_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, const float* __restrict__ gamma,
+                   const float* __restrict__ rowscale, bf16* __restrict__ dy, float* __restrict__ dgamma,
+                   float* __restrict__ dbias, int M, int C, int tokens) {
+    __shared__ float red[4][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2;
+    float4 ag[CP_MAXV], ab[CP_MAXV];
+#pragma unroll
+    for (int k = 0; k < CP_MAXV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
+    const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
+    for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
+        const float dp = rowscale ? rowscale[row / tokens] : 1.0f;
+#pragma unroll
+        for (int k = 0; k < CP_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) {
+                const float4 d = ((const float4*)(dx + (size_t)row * C))[i];
+                const float4 g = ((const float4*)gamma)[i];
+                const bf16x4 yy = ((const bf16x4*)(y + (size_t)row * C))[i];
+                const float e0 = d.x * dp, e1 = d.y * dp, e2 = d.z * dp, e3 = d.w * dp;
+                ag[k].x += e0 * bf2f(yy[0]); ag[k].y += e1 * bf2f(yy[1]); ag[k].z += e2 * bf2f(yy[2]); ag[k].w += e3 * bf2f(yy[3]);
+                bf16x4 o = {f2bf(e0 * g.x), f2bf(e1 * g.y), f2bf(e2 * g.z), f2bf(e3 * g.w)};
+                ((bf16x4*)(dy + (size_t)row * C))[i] = o;
+                ab[k].x += bf2f(o[0]); ab[k].y += bf2f(o[1]); ab[k].z += bf2f(o[2]); ab[k].w += bf2f(o[3]);
+            }
+        }
+    }
+    block_col_atomic(ag, dgamma, nv, red);
+    block_col_atomic(ab, dbias, nv, red);
+}
+
+// out[c] += sum_m y[m][col0 + c]
+__global__ __launch_bounds__(256)
+void colsum_kernel(const bf16* __restrict__ y, int ld, int col0, int ncols, int M, float* __restrict__ out) {
+    __shared__ float red[4][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int row_end = min((int)(blockIdx.y + 1) * 128, M);
+    if (c < ncols)
+        for (int row = blockIdx.y * 128 + wave; row < row_end; row += 4) {
+            const bf16x4 v = *(const bf16x4*)(y + (size_t)row * ld + col0 + c);
+            acc.x += bf2f(v[0]); acc.y += bf2f(v[1]); acc.z += bf2f(v[2]); acc.w += bf2f(v[3]);
+        }
+    ((float4*)red[wave])[lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < ncols) {
+        float4 s = ((float4*)red[0])[lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const float4 a = ((float4*)red[q])[lane]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+        atomicAdd(out + c, s.x); atomicAdd(out + c + 1, s.y); atomicAdd(out + c + 2, s.z); atomicAdd(out + c + 3, s.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// loss = mean smooth_l1(out, target; beta) over count*C elements (engine_for_cyclical.py:147-163),
+// fused with its gradient (bf16), rows >= count produce zero gradient.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void smooth_l1_kernel(const float* __restrict__ out, const float* __restrict__ target, const int* __restrict__ count,
+                      float beta, int l2, float loss_scale, float* __restrict__ loss, bf16* __restrict__ dout,
+                      int Mmax, int C) {
+    __shared__ float red[4];
+    const int n_valid = min(*count, Mmax);
+    const size_t nv = (size_t)Mmax * C / 4, valid = (size_t)n_valid * C / 4;
+    const float inv = loss_scale / ((float)n_valid * (float)C);
+    float part = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        bf16x4 g = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        if (i < valid) {
+            const float4 o = ((const float4*)out)[i], t = ((const float4*)target)[i];
+            const float d[4] = {o.x - t.x, o.y - t.y, o.z - t.z, o.w - t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = fabsf(d[j]);
+                float l, gr;
+                if (l2) { l = d[j] * d[j]; gr = 2.0f * d[j]; }
+                else if (a < beta) { l = 0.5f * d[j] * d[j] / beta; gr = d[j] / beta; }
+                else { l = a - 0.5f * beta; gr = d[j] > 0.f ? 1.0f : (d[j] < 0.f ? -1.0f : 0.f); }
+                part += l;
+                g[j] = f2bf(gr * inv);
+            }
+        }
+        ((bf16x4*)dout)[i] = g;
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// ------------------------------------------------------------------------------------------
+// token-assembly backward (modeling_cyclical.py:179-192):  dpatch = (1-w) * dx[:,1:],
+// dcls += sum_b dx[b,0], dmask_token += sum_masked dx
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ mask, bf16* __restrict__ dpatch,
+                      float* __restrict__ dcls, float* __restrict__ dmask, int B, int P, int C) {
+    __shared__ float red[4][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2, N = P + 1;
+    float4 ac[CP_MAXV], am[CP_MAXV];
+#pragma unroll
+    for (int k = 0; k < CP_MAXV; ++k) { ac[k] = make_float4(0.f, 0.f, 0.f, 0.f); am[k] = ac[k]; }
+    const int M = B * N;
+    const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
+    for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
+        const int b = row / N, t = row - b * N;
+        const bool is_cls = t == 0;
+        const bool masked = !is_cls && mask[b * P + t - 1] != 0;
+#pragma unroll
+        for (int k = 0; k < CP_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) {
+                const float4 d = ((const float4*)(dx + (size_t)row * C))[i];
+                if (is_cls) { ac[k].x += d.x; ac[k].y += d.y; ac[k].z += d.z; ac[k].w += d.w; }
+                else {
+                    if (masked) { am[k].x += d.x; am[k].y += d.y; am[k].z += d.z; am[k].w += d.w; }
+                    const float m = masked ? 0.f : 1.f;
+                    bf16x4 o = {f2bf(d.x * m), f2bf(d.y * m), f2bf(d.z * m), f2bf(d.w * m)};
+                    ((bf16x4*)(dpatch + ((size_t)b * P + t - 1) * C))[i] = o;
+                }
+            }
+        }
+    }
+    block_col_atomic(ac, dcls, nv, red);
+    block_col_atomic(am, dmask, nv, red);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched bf16 transposes (weights -> W^T copies for the dgrad GEMMs), 64x64 tiles through LDS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void transpose_batch_kernel(const TransposeDesc* __restrict__ descs, int ndesc) {
+    __shared__ bf16 tile[64][66];
+    int lo = 0, hi = ndesc - 1;
+    const int t = blockIdx.x;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
+    const TransposeDesc d = descs[lo];
+    const int local = t - d.tile0, tc = (d.cols + 63) / 64;
+    const int tr0 = (local / tc) * 64, tc0 = (local % tc) * 64;
+    if (tr0 >= d.rows) return;
+    const bf16* src = (const bf16*)d.src; bf16* dst = (bf16*)d.dst;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (tr0 + r < d.rows && tc0 + c < d.cols) ? src[(size_t)(tr0 + r) * d.cols + tc0 + c] : f2bf(0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (tr0 + r < d.rows && tc0 + c < d.cols) dst[(size_t)(tc0 + c) * d.rows + tr0 + r] = tile[r][c];
+    }
+}
+
+// scales[(layer*2 + branch)*B + b] : 1/keep or 0 (timm drop_path, modeling_finetune.py:51-62); rate 0 -> 1
+__global__ void droppath_kernel(float* __restrict__ scales, const float* __restrict__ rates, int depth, int B,
+                                uint32_t seed, uint32_t step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= depth * 2 * B) return;
+    const int b = i % B, lb = i / B, layer = lb >> 1, br = lb & 1;
+    const float r = rates[layer];
+    float v = 1.0f;
+    if (r > 0.f) {
+        const uint32_t key = uvit_hash32(seed ^ ((step * 2u * depth + 2u * layer + br + 1u) * 0x9E3779B9u));
+        v = uvit_hash32((uint32_t)b ^ key) >= uvit_drop_threshold(r) ? 1.0f / (1.0f - r) : 0.f;
+    }
+    scales[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+int uvit_im2col_launch(const float* img, void* cols, int B, int Cin, int S, int p, hipStream_t s) {
+    if (B <= 0 || p % 8 || S % p || S % 4) return UVIT_ERR_SHAPE;
+    const size_t total = (size_t)B * (S / p) * (S / p) * (Cin * p * p / 8);
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, s, img, (bf16*)cols, B, Cin, S, p);
+    return uvit_check_launch();
+}
+int uvit_mask_compact_launch(const int64_t* mask, int* rowidx, int* count, int B, int P, hipStream_t s) {
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(1), dim3(1024), 0, s, mask, rowidx, count, B, P);
+    return uvit_check_launch();
+}
+int uvit_set_cls_launch(float* x, const float* cls, const float* pos, int B, int N, int C, hipStream_t s) {
+    if (pos) return UVIT_ERR_ARG;   // absolute position embedding: not on the configured path (use_abs_pos_emb=False)
+    hipLaunchKernelGGL(set_cls_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, x, cls, B, N, C);
+    return uvit_check_launch();
+}
+int uvit_relpos_gather_launch(const float* table, const int* index, float* biasP, int H, int N, int NP, hipStream_t s) {
+    hipLaunchKernelGGL(relpos_gather_kernel, dim3(grid_for((size_t)H * NP * NP, 256)), dim3(256), 0, s, table, index, biasP, H, N, NP);
+    return uvit_check_launch();
+}
+int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, float* dtable, int H, int N, int NP,
+                               hipStream_t s) {
+    const int g = (int)(sqrtf((float)(N - 1)) + 0.5f);
+    const int ntable = (2 * g - 1) * (2 * g - 1) + 3;
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3(H, 8), dim3(256), ntable * sizeof(float), s, slab, nslab, index, dtable, H, N, NP, ntable);
+    return uvit_check_launch();
+}
+int uvit_ls_bwd_launch(const float* dx, const void* y, const float* gamma, const float* rowscale, void* dy,
+                       float* dgamma, float* dbias, int M, int C, int tokens, hipStream_t s) {
+    if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(ls_bwd_kernel, dim3((M + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, (const bf16*)y, gamma, rowscale,
+                       (bf16*)dy, dgamma, dbias, M, C, tokens);
+    return uvit_check_launch();
+}
+int uvit_colsum_launch(const void* y, int ld, int col0, int ncols, int M, float* out, hipStream_t s) {
+    if (ncols % 4 || col0 % 4 || ld % 4) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((ncols + 255) / 256, (M + 127) / 128), dim3(256), 0, s, (const bf16*)y, ld, col0, ncols, M, out);
+    return uvit_check_launch();
+}
+int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,
+                          float* loss, void* dout, int Mmax, int C, hipStream_t s) {
+    if (C % 4) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for((size_t)Mmax * C / 4, 256)), dim3(256), 0, s, out, target, count, beta, l2,
+                       loss_scale, loss, (bf16*)dout, Mmax, C);
+    return uvit_check_launch();
+}
+int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch, float* dcls, float* dmask_token, int B,
+                          int P, int C, hipStream_t s) {
+    if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(token_bwd_kernel, dim3((B * (P + 1) + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
+                       dcls, dmask_token, B, P, C);
+    return uvit_check_launch();
+}
+int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int total_tiles, hipStream_t s) {
+    if (ndesc <= 0 || total_tiles <= 0) return UVIT_OK;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, s, (const TransposeDesc*)descs_dev, ndesc);
+    return uvit_check_launch();
+}
+int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step, hipStream_t s) {
+    hipLaunchKernelGGL(droppath_kernel, dim3((depth * 2 * B + 255) / 256), dim3(256), 0, s, scales, rates_dev, depth, B, seed, step);
+    return uvit_check_launch();
+}

@@ -1,0 +1,632 @@
+// Engine: arena layout, workspace plan and the launch sequence of the data2vec ViT step
+// (engine_for_cyclical.py:58-186 over modeling_cyclical.py:170-225) on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/uvit.h"
+#include "common.h"
+#include "uvit_internal.h"
+
+#define CHECK(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define HIPCHECK(x) do { if ((x) != hipSuccess) return UVIT_ERR_LAUNCH; } while (0)
+
+// ------------------------------------------------------------------------------------------
+// layout
+// ------------------------------------------------------------------------------------------
+struct LayerOff { size_t n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2; };
+struct Layout {
+    size_t cls, mask_tok, pew, peb, relt, normw, normb, lmw, lmb;
+    LayerOff L[UVIT_MAX_DEPTH];
+    size_t n_total, n_decay;
+    std::vector<uvit_layout_entry> entries;
+};
+
+static size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+static int cfg_ok(const uvit_config* c) {
+    if (!c) return UVIT_ERR_ARG;
+    if (c->depth < 1 || c->depth > UVIT_MAX_DEPTH || c->num_heads < 1 || c->embed_dim != c->num_heads * 64) return UVIT_ERR_SHAPE;
+    if (c->embed_dim % 64 || c->mlp_hidden % 64 || c->patch_size % 8 || c->img_size % c->patch_size) return UVIT_ERR_SHAPE;
+    if ((c->in_chans * c->patch_size * c->patch_size) % 64) return UVIT_ERR_SHAPE;
+    const int g = c->img_size / c->patch_size;
+    if (g * g + 1 > 208 || c->batch < 1 || c->use_abs_pos_emb) return UVIT_ERR_SHAPE;
+    return UVIT_OK;
+}
+
+static void build_layout(const uvit_config* c, Layout& lo) {
+    const int64_t C = c->embed_dim, Hd = c->mlp_hidden, g = c->img_size / c->patch_size;
+    const int64_t Kpe = (int64_t)c->in_chans * c->patch_size * c->patch_size;
+    size_t off = 0;
+    auto add = [&](const std::string& name, std::vector<int64_t> shape, int decay) -> size_t {
+        uvit_layout_entry e;
+        memset(&e, 0, sizeof(e));
+        snprintf(e.name, sizeof(e.name), "%s", name.c_str());
+        e.offset = (int64_t)off; e.ndim = (int)shape.size(); e.decay = decay; e.numel = 1;
+        for (size_t i = 0; i < shape.size(); ++i) { e.shape[i] = shape[i]; e.numel *= shape[i]; }
+        lo.entries.push_back(e);
+        const size_t at = off;
+        off = align64(off + (size_t)e.numel);
+        return at;
+    };
+    auto blk = [](int i, const char* s) { return "blocks." + std::to_string(i) + "." + s; };
+    // ---- decay group: everything that is not 1-D, not *.bias, not in {pos_embed, cls_token} ----
+    lo.mask_tok = add("mask_token", {1, 1, C}, 1);
+    if (c->use_shared_rel_pos_bias) lo.relt = add("rel_pos_bias.relative_position_bias_table", {(2 * g - 1) * (2 * g - 1) + 3, c->num_heads}, 1);
+    else lo.relt = (size_t)-1;
+    lo.pew = add("patch_embed.proj.weight", {C, c->in_chans, c->patch_size, c->patch_size}, 1);
+    (void)Kpe;
+    for (int i = 0; i < c->depth; ++i) {
+        lo.L[i].qkvw = add(blk(i, "attn.qkv.weight"), {3 * C, C}, 1);
+        lo.L[i].projw = add(blk(i, "attn.proj.weight"), {C, C}, 1);
+        lo.L[i].fc1w = add(blk(i, "mlp.fc1.weight"), {Hd, C}, 1);
+        lo.L[i].fc2w = add(blk(i, "mlp.fc2.weight"), {C, Hd}, 1);
+    }
+    lo.lmw = add("lm_head.weight", {C, C}, 1);
+    lo.n_decay = off;
+    // ---- no-decay group ----
+    lo.cls = add("cls_token", {1, 1, C}, 0);
+    lo.peb = add("patch_embed.proj.bias", {C}, 0);
+    for (int i = 0; i < c->depth; ++i) {
+        lo.L[i].g1 = add(blk(i, "gamma_1"), {C}, 0);
+        lo.L[i].g2 = add(blk(i, "gamma_2"), {C}, 0);
+        lo.L[i].n1w = add(blk(i, "norm1.weight"), {C}, 0);
+        lo.L[i].n1b = add(blk(i, "norm1.bias"), {C}, 0);
+        lo.L[i].qb = add(blk(i, "attn.q_bias"), {C}, 0);
+        lo.L[i].vb = add(blk(i, "attn.v_bias"), {C}, 0);
+        lo.L[i].projb = add(blk(i, "attn.proj.bias"), {C}, 0);
+        lo.L[i].n2w = add(blk(i, "norm2.weight"), {C}, 0);
+        lo.L[i].n2b = add(blk(i, "norm2.bias"), {C}, 0);
+        lo.L[i].fc1b = add(blk(i, "mlp.fc1.bias"), {Hd}, 0);
+        lo.L[i].fc2b = add(blk(i, "mlp.fc2.bias"), {C}, 0);
+    }
+    lo.normw = add("norm.weight", {C}, 0);
+    lo.normb = add("norm.bias", {C}, 0);
+    lo.lmb = add("lm_head.bias", {C}, 0);
+    lo.n_total = off;
+}
+
+// ------------------------------------------------------------------------------------------
+// engine
+// ------------------------------------------------------------------------------------------
+struct LayerActs {
+    bf16 *ln1, *qkv, *attn, *projout, *ln2, *h, *a, *mlpout;
+    float *mean1, *rstd1, *mean2, *rstd2, *lse;
+};
+
+struct uvit_engine {
+    uvit_config cfg;
+    uvit_buffers buf;
+    Layout lo;
+    int B, P, N, NP, C, Hd, H, Kpe, M, Mpad, BP, BPpad, chunk, nchunk;
+    int cur_B;             // batch of the last forward
+    // workspace
+    bf16* cols;
+    float* X[UVIT_MAX_DEPTH + 1];
+    float* XM[UVIT_MAX_DEPTH];
+    LayerActs acts[UVIT_MAX_DEPTH];
+    LayerActs tacts;       // teacher scratch (nothing saved)
+    float *tX[2], *tXM;
+    int *rowidx, *count;
+    bf16 *normed, *dout, *dnormed, *dpatch;
+    float *meanF, *rstdF, *outputs, *targets;
+    float *biasP_s, *biasP_t, *slabs, *delta;
+    float *dXa, *dXb;
+    bf16 *dY, *dH, *dLN, *dAttn, *dqkv;
+    float *dp_scales, *dp_rates;
+    float *loss, *gnorm; double* sumsq;
+    TransposeDesc* tdesc; int n_tdesc, n_ttiles;
+    int64_t* mask_copy;
+    bool slab_started;
+    bool last_dropout; uint32_t last_seed, last_it;
+    // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    size_t prof_used = 0;
+};
+
+struct Bump {
+    char* base; size_t off, cap;
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+static void plan_workspace(uvit_engine* e, Bump& b) {
+    const uvit_config& c = e->cfg;
+    const size_t Mp = e->Mpad, C = e->C, Hd = e->Hd, BPp = e->BPpad;
+    auto acts = [&](LayerActs& a) {
+        a.ln1 = b.take<bf16>(Mp * C); a.qkv = b.take<bf16>(Mp * 3 * C); a.attn = b.take<bf16>(Mp * C);
+        a.projout = b.take<bf16>(Mp * C); a.ln2 = b.take<bf16>(Mp * C); a.h = b.take<bf16>(Mp * Hd);
+        a.a = b.take<bf16>(Mp * Hd); a.mlpout = b.take<bf16>(Mp * C);
+        a.mean1 = b.take<float>(Mp); a.rstd1 = b.take<float>(Mp); a.mean2 = b.take<float>(Mp); a.rstd2 = b.take<float>(Mp);
+        a.lse = b.take<float>((size_t)e->B * e->H * e->N);
+    };
+    e->cols = b.take<bf16>(BPp * e->Kpe);
+    for (int i = 0; i <= c.depth; ++i) e->X[i] = b.take<float>(Mp * C);
+    for (int i = 0; i < c.depth; ++i) { e->XM[i] = b.take<float>(Mp * C); acts(e->acts[i]); }
+    acts(e->tacts);
+    e->tX[0] = b.take<float>(Mp * C); e->tX[1] = b.take<float>(Mp * C); e->tXM = b.take<float>(Mp * C);
+    e->rowidx = b.take<int>(e->BP + 64); e->count = b.take<int>(64);
+    e->normed = b.take<bf16>(BPp * C); e->dout = b.take<bf16>(BPp * C); e->dnormed = b.take<bf16>(BPp * C);
+    e->dpatch = b.take<bf16>(BPp * C);
+    e->meanF = b.take<float>(BPp); e->rstdF = b.take<float>(BPp);
+    e->outputs = b.take<float>(BPp * C); e->targets = b.take<float>(BPp * C);
+    const size_t bias_n = (size_t)e->H * e->NP * e->NP;
+    e->biasP_s = b.take<float>(bias_n); e->biasP_t = b.take<float>(bias_n);
+    e->slabs = b.take<float>(bias_n * e->nchunk);
+    e->delta = b.take<float>((size_t)e->B * e->H * e->N);
+    e->dXa = b.take<float>(Mp * C); e->dXb = b.take<float>(Mp * C);
+    e->dY = b.take<bf16>(Mp * C); e->dH = b.take<bf16>(Mp * Hd); e->dLN = b.take<bf16>(Mp * C);
+    e->dAttn = b.take<bf16>(Mp * C); e->dqkv = b.take<bf16>(Mp * 3 * C);
+    e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->B); e->dp_rates = b.take<float>(c.depth);
+    e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
+    e->tdesc = b.take<TransposeDesc>(5 * c.depth + 2);
+    e->mask_copy = b.take<int64_t>(e->BP + 64);
+}
+
+static void fill_dims(uvit_engine* e) {
+    const uvit_config& c = e->cfg;
+    const int g = c.img_size / c.patch_size;
+    e->B = c.batch; e->P = g * g; e->N = e->P + 1; e->NP = 208; e->C = c.embed_dim; e->Hd = c.mlp_hidden;
+    e->H = c.num_heads; e->Kpe = c.in_chans * c.patch_size * c.patch_size;
+    e->M = e->B * e->N; e->Mpad = (int)roundup(e->M, 128); e->BP = e->B * e->P; e->BPpad = (int)roundup(e->BP, 128);
+    e->chunk = c.bias_chunk > 0 ? c.bias_chunk : 8;
+    e->nchunk = (e->B + e->chunk - 1) / e->chunk;
+    e->cur_B = e->B;
+}
+
+extern "C" int uvit_version(void) { return UVIT_VERSION; }
+
+extern "C" int uvit_layout_count(const uvit_config* cfg) {
+    if (cfg_ok(cfg)) return UVIT_ERR_SHAPE;
+    Layout lo; build_layout(cfg, lo);
+    return (int)lo.entries.size();
+}
+extern "C" int uvit_layout_get(const uvit_config* cfg, int index, uvit_layout_entry* out) {
+    if (cfg_ok(cfg) || !out) return UVIT_ERR_SHAPE;
+    Layout lo; build_layout(cfg, lo);
+    if (index < 0 || index >= (int)lo.entries.size()) return UVIT_ERR_ARG;
+    *out = lo.entries[index];
+    return UVIT_OK;
+}
+extern "C" int64_t uvit_arena_numel(const uvit_config* cfg, int64_t* n_decay_out) {
+    if (cfg_ok(cfg)) return UVIT_ERR_SHAPE;
+    Layout lo; build_layout(cfg, lo);
+    if (n_decay_out) *n_decay_out = (int64_t)lo.n_decay;
+    return (int64_t)lo.n_total;
+}
+extern "C" int64_t uvit_workspace_bytes(const uvit_config* cfg) {
+    if (cfg_ok(cfg)) return UVIT_ERR_SHAPE;
+    uvit_engine tmp;
+    tmp.cfg = *cfg;
+    fill_dims(&tmp);
+    Bump b{nullptr, 0, 0};
+    plan_workspace(&tmp, b);
+    return (int64_t)roundup(b.off, 4096) + 4096;
+}
+
+extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_buffers* bufs, uvit_stream stream, int* err_out) {
+    auto fail = [&](int rc) -> uvit_engine* { if (err_out) *err_out = rc; return nullptr; };
+    if (cfg_ok(cfg) || !bufs) return fail(UVIT_ERR_SHAPE);
+    if (!bufs->params || !bufs->grads || !bufs->adam_m || !bufs->adam_v || !bufs->ema || !bufs->params_bf16 ||
+        !bufs->params_bf16_t || !bufs->ema_bf16 || !bufs->workspace) return fail(UVIT_ERR_ARG);
+    if (cfg->use_shared_rel_pos_bias && !bufs->rel_index) return fail(UVIT_ERR_ARG);
+    if (bufs->workspace_bytes < uvit_workspace_bytes(cfg)) return fail(UVIT_ERR_WORKSPACE);
+    uvit_engine* e = new uvit_engine();
+    e->cfg = *cfg; e->buf = *bufs;
+    fill_dims(e);
+    build_layout(cfg, e->lo);
+    Bump b{(char*)bufs->workspace, 0, (size_t)bufs->workspace_bytes};
+    plan_workspace(e, b);
+    hipStream_t s = (hipStream_t)stream;
+    // pad rows of every activation buffer must be (and stay) zero: TN GEMMs reduce over them
+    if (hipMemsetAsync(bufs->workspace, 0, b.off, s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
+    // drop-path rates linspace(0, rate, depth)  (modeling_cyclical.py:94-96)
+    std::vector<float> rates(cfg->depth);
+    for (int i = 0; i < cfg->depth; ++i)
+        rates[i] = cfg->depth > 1 ? (float)((double)cfg->drop_path_rate * i / (cfg->depth - 1)) : 0.f;
+    // transposed-copy descriptors
+    std::vector<TransposeDesc> td;
+    int tiles = 0;
+    const char* src = (const char*)bufs->params_bf16; char* dst = (char*)bufs->params_bf16_t;
+    auto addT = [&](size_t off, int rows, int cols) {
+        TransposeDesc d; d.src = src + off * 2; d.dst = dst + off * 2; d.rows = rows; d.cols = cols; d.tile0 = tiles; d.pad = 0;
+        tiles += ((rows + 63) / 64) * ((cols + 63) / 64);
+        td.push_back(d);
+    };
+    for (int i = 0; i < cfg->depth; ++i) {
+        addT(e->lo.L[i].qkvw, 3 * e->C, e->C); addT(e->lo.L[i].projw, e->C, e->C);
+        addT(e->lo.L[i].fc1w, e->Hd, e->C); addT(e->lo.L[i].fc2w, e->C, e->Hd);
+    }
+    addT(e->lo.lmw, e->C, e->C);
+    e->n_tdesc = (int)td.size(); e->n_ttiles = tiles;
+    if (hipMemcpyAsync(e->dp_rates, rates.data(), rates.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(e->tdesc, td.data(), td.size() * sizeof(TransposeDesc), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
+    e->slab_started = false; e->last_dropout = false; e->last_seed = 0; e->last_it = 0;
+    if (err_out) *err_out = UVIT_OK;
+    return e;
+}
+
+extern "C" void uvit_engine_destroy(uvit_engine* e) {
+    if (!e) return;
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches) {
+    if (!e) return UVIT_ERR_ARG;
+    if (enable && e->prof_ev.empty()) {
+        e->prof_ev.resize((size_t)(max_launches > 0 ? max_launches : 4096) * 2);
+        for (auto& ev : e->prof_ev) if (hipEventCreate(&ev) != hipSuccess) return UVIT_ERR_LAUNCH;
+    }
+    e->prof_on = enable != 0;
+    if (enable) e->prof_used = 0;
+    return UVIT_OK;
+}
+
+extern "C" int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch) {
+    if (!e || !total_ms || !launches) return UVIT_ERR_ARG;
+    double t = 0.0; int n = 0;
+    for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) != hipSuccess) return UVIT_ERR_LAUNCH;
+        t += ms; ++n;
+    }
+    *total_ms = t; *launches = n;
+    if (flops_per_launch) *flops_per_launch = 2.0 * (double)e->cur_B * e->N * (double)e->Hd * e->C;
+    return UVIT_OK;
+}
+
+extern "C" int uvit_engine_sync_shadows(uvit_engine* e, int which, uvit_stream stream) {
+    if (!e) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (which & 1) {
+        CHECK(uvit_cast_bf16_launch(e->buf.params, e->buf.params_bf16, e->lo.n_total, s));
+        CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
+    }
+    if (which & 2) CHECK(uvit_cast_bf16_launch(e->buf.ema, e->buf.ema_bf16, e->lo.n_total, s));
+    return UVIT_OK;
+}
+
+// ---- forward ----
+struct Weights { const float* f; const bf16* b; };
+
+static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x_in, float* x_mid, float* x_out,
+                         LayerActs& a, bool save, const float* biasP, const float* dp1, const float* dp2,
+                         float pdrop, uint32_t seed, int Bc, hipStream_t s) {
+    const LayerOff& o = e->lo.L[l];
+    const int M = Bc * e->N, C = e->C, Hd = e->Hd;
+    CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, M, C, e->cfg.ln_eps, s));
+    GemmEpi q; q.out = a.qkv; q.bias = w.f + o.qb; q.bias2 = w.f + o.vb; q.ldo = 3 * C;
+    CHECK(uvit_gemm_nt_launch(EPI_QKV, a.ln1, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
+    CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s));
+    GemmEpi p; p.out = x_mid; p.out2 = save ? a.projout : nullptr; p.bias = w.f + o.projb; p.gamma = w.f + o.g1;
+    p.resid = x_in; p.rowscale = dp1; p.ldo = C; p.tokens = e->N;
+    CHECK(uvit_gemm_nt_launch(EPI_RESID, a.attn, w.b + o.projw, M, C, C, C, C, &p, s));
+    CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, M, C, e->cfg.ln_eps, s));
+    GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
+    const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
+    CHECK(uvit_gemm_nt_launch(EPI_GELU, a.ln2, w.b + o.fc1w, M, Hd, C, C, C, &f1, s));
+    if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
+    GemmEpi f2; f2.out = x_out; f2.out2 = save ? a.mlpout : nullptr; f2.bias = w.f + o.fc2b; f2.gamma = w.f + o.g2;
+    f2.resid = x_mid; f2.rowscale = dp2; f2.ldo = C; f2.tokens = e->N;
+    CHECK(uvit_gemm_nt_launch(EPI_RESID, a.a, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
+    return UVIT_OK;
+}
+
+// patch embedding + token assembly into x0 (modeling_cyclical.py:171-192)
+static int embed(uvit_engine* e, const Weights& w, const int64_t* mask, float* x0, int Bc, hipStream_t s) {
+    GemmEpi pe; pe.out = x0; pe.bias = w.f + e->lo.peb; pe.mask = mask; pe.mask_token = w.f + e->lo.mask_tok;
+    pe.ldo = e->C; pe.patches = e->P;
+    CHECK(uvit_gemm_nt_launch(EPI_PATCH, e->cols, w.b + e->lo.pew, Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
+    CHECK(uvit_set_cls_launch(x0, w.f + e->lo.cls, nullptr, Bc, e->N, e->C, s));
+    return UVIT_OK;
+}
+
+static int run_forward(uvit_engine* e, int which, const float* images, const int64_t* mask, int Bc, bool save_student,
+                       bool dropout, uint32_t seed, uint32_t it, const uvit_step_params* hp_targets, bool cols_ready,
+                       hipStream_t s) {
+    if (Bc < 1 || Bc > e->B) return UVIT_ERR_SHAPE;
+    const bool teacher = which == 1;
+    Weights w{teacher ? e->buf.ema : e->buf.params, (const bf16*)(teacher ? e->buf.ema_bf16 : e->buf.params_bf16)};
+    if (!cols_ready) CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
+    float* biasP = nullptr;
+    if (e->cfg.use_shared_rel_pos_bias) {
+        biasP = teacher ? e->biasP_t : e->biasP_s;
+        CHECK(uvit_relpos_gather_launch(w.f + e->lo.relt, e->buf.rel_index, biasP, e->H, e->N, e->NP, s));
+    }
+    const bool dp_on = dropout && !teacher && e->cfg.drop_path_rate > 0.f;
+    const float pdrop = (dropout && !teacher) ? e->cfg.attn_drop_rate : 0.f;
+    if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, Bc, seed, it, s));
+    const uint32_t aseed = uvit_hash32(seed ^ (it * 0x85EBCA6Bu + 0x1234567u));
+    if (!teacher) { e->last_dropout = dropout; e->last_seed = aseed; e->last_it = it; }
+    const bool use_saved = !teacher || !hp_targets;   // drop-in forward keeps every layer for either weight set
+    float* x0 = use_saved ? e->X[0] : e->tX[0];
+    CHECK(embed(e, w, mask, x0, Bc, s));
+    int n_t = 0;
+    for (int l = 0; l < e->cfg.depth; ++l) {
+        const float* dp1 = dp_on ? e->dp_scales + (size_t)(2 * l) * Bc : nullptr;
+        const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * Bc : nullptr;
+        if (use_saved) {
+            CHECK(forward_layer(e, w, l, e->X[l], e->XM[l], e->X[l + 1], e->acts[l], save_student && !teacher, biasP, dp1, dp2,
+                                pdrop, aseed, Bc, s));
+        } else {
+            float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
+            CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, nullptr, nullptr, 0.f, 0, Bc, s));
+            bool is_t = false;
+            for (int k = 0; k < hp_targets->n_target_layers; ++k) is_t |= hp_targets->target_layers[k] == l;
+            if (is_t) {
+                if (!hp_targets->target_layer_norm_last) return UVIT_ERR_ARG;
+                CHECK(uvit_target_accum_launch(xout, e->rowidx, e->count, e->targets, n_t == 0, Bc * e->P, e->C, 1e-5f, s));
+                ++n_t;
+            }
+        }
+    }
+    if (teacher && hp_targets) {
+        if (n_t == 0) return UVIT_ERR_ARG;
+        CHECK(uvit_target_finalize_launch(e->targets, e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
+    }
+    e->cur_B = Bc;
+    return UVIT_OK;
+}
+
+extern "C" int uvit_engine_forward_features(uvit_engine* e, int which, const float* images, const int64_t* mask, int batch,
+                                            int train_dropout, uint32_t seed, uint32_t it, uvit_stream stream) {
+    if (!e || !images || (which != 0 && which != 1)) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (mask) CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, batch, e->P, s));
+    return run_forward(e, which, images, mask, batch, false, train_dropout != 0, seed, it, nullptr, false, s);
+}
+
+static int head_forward(uvit_engine* e, const Weights& w, int Bc, bool all_tokens, float* out, hipStream_t s) {
+    const int BP = Bc * e->P;
+    if (all_tokens) {
+        // every patch row: identity index list b*N+1+p built by compacting an all-ones mask is avoided --
+        // normalise all tokens, then run the head on the patch rows of each sample
+        CHECK(uvit_ln_fwd_launch(e->X[e->cfg.depth], w.f + e->lo.normw, w.f + e->lo.normb, e->acts[0].ln1, e->acts[0].mean1,
+                                 e->acts[0].rstd1, Bc * e->N, e->C, e->cfg.ln_eps, s));
+        for (int b = 0; b < Bc; ++b) {
+            GemmEpi h; h.out = out + (size_t)b * e->P * e->C; h.bias = w.f + e->lo.lmb; h.ldo = e->C;
+            CHECK(uvit_gemm_nt_launch(EPI_F32, e->acts[0].ln1 + ((size_t)b * e->N + 1) * e->C, w.b + e->lo.lmw, e->P, e->C, e->C,
+                                      e->C, e->C, &h, s));
+        }
+        return UVIT_OK;
+    }
+    CHECK(uvit_ln_fwd_gather_launch(e->X[e->cfg.depth], e->rowidx, e->count, w.f + e->lo.normw, w.f + e->lo.normb, e->normed,
+                                    e->meanF, e->rstdF, BP, e->C, e->cfg.ln_eps, s));
+    GemmEpi h; h.out = out; h.bias = w.f + e->lo.lmb; h.ldo = e->C;
+    CHECK(uvit_gemm_nt_launch(EPI_F32, e->normed, w.b + e->lo.lmw, BP, e->C, e->C, e->C, e->C, &h, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float* out, int32_t* count_dev, uvit_stream stream) {
+    if (!e || !out) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool teacher = which == 1;
+    Weights w{teacher ? e->buf.ema : e->buf.params, (const bf16*)(teacher ? e->buf.ema_bf16 : e->buf.params_bf16)};
+    CHECK(head_forward(e, w, e->cur_B, all_tokens != 0, out, s));
+    if (count_dev && !all_tokens) HIPCHECK(hipMemcpyAsync(count_dev, e->count, sizeof(int), hipMemcpyDeviceToDevice, s));
+    return UVIT_OK;
+}
+
+extern "C" void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer) {
+    if (!e || !name) return nullptr;
+    const std::string n(name);
+    if (n == "x" && layer >= 0 && layer <= e->cfg.depth) return e->X[layer];
+    if (n == "xm" && layer >= 0 && layer < e->cfg.depth) return e->XM[layer];
+    if (n == "loss") return e->loss;
+    if (n == "grad_norm") return e->gnorm;
+    if (n == "targets") return e->targets;
+    if (n == "outputs") return e->outputs;
+    if (n == "count") return e->count;
+    if (n == "dx") return e->dXa;
+    return nullptr;
+}
+
+// ---- training step ----
+extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
+                               uvit_stream stream) {
+    if (!e || !images || !mask || !hp || hp->n_target_layers < 1 || hp->n_target_layers > UVIT_MAX_DEPTH) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int Bc = e->B, BP = e->BP, C = e->C;
+    Layout& lo = e->lo;
+    // zero the accumulated (atomic) gradient ranges + step scalars
+    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.pew * sizeof(float), s));                       // mask_token, rel table
+    HIPCHECK(hipMemsetAsync(e->buf.grads + lo.n_decay, 0, (lo.n_total - lo.n_decay) * sizeof(float), s));
+    HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), s));
+    e->slab_started = false;
+    HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
+    // teacher (EMA weights, eval mode, no grad): engine_for_cyclical.py:68-122
+    CHECK(run_forward(e, 1, images, nullptr, Bc, false, false, 0, 0, hp, false, s));
+    // student: engine_for_cyclical.py:124-128
+    CHECK(run_forward(e, 0, images, mask, Bc, true, hp->train_dropout != 0, hp->seed, hp->it, nullptr, true, s));
+    Weights w{e->buf.params, (const bf16*)e->buf.params_bf16};
+    CHECK(head_forward(e, w, Bc, false, e->outputs, s));
+    // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163
+    const float ls = hp->loss_scale == -1.0f ? 1.0f : hp->loss_scale;
+    CHECK(uvit_smooth_l1_launch(e->outputs, e->targets, e->count, hp->l1_beta, hp->l2_loss, ls, e->loss, e->dout, BP, C, s));
+    // lm_head backward
+    float* g = e->buf.grads;
+    const bf16* wt = (const bf16*)e->buf.params_bf16_t;
+    CHECK(uvit_colsum_launch(e->dout, C, 0, C, BP, g + lo.lmb, s));
+    CHECK(uvit_gemm_tn_launch(e->dout, e->normed, e->BPpad, C, C, C, C, g + lo.lmw, C, s));
+    GemmEpi d; d.out = e->dnormed; d.ldo = C;
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout, wt + lo.lmw, BP, C, C, C, C, &d, s));
+    // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
+    HIPCHECK(hipMemsetAsync(e->dXa, 0, (size_t)e->M * C * sizeof(float), s));
+    CHECK(uvit_ln_bwd_scatter_launch(e->dnormed, e->X[e->cfg.depth], e->rowidx, e->count, e->meanF, e->rstdF,
+                                     e->buf.params + lo.normw, e->dXa, g + lo.normw, g + lo.normb, BP, C, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_params* hp, uvit_stream stream) {
+    if (!e || l < 0 || l >= e->cfg.depth) return UVIT_ERR_ARG;
+    (void)hp;
+    hipStream_t s = (hipStream_t)stream;
+    const LayerOff& o = e->lo.L[l];
+    LayerActs& a = e->acts[l];
+    const int M = e->M, Mp = (int)roundup(e->M, 64), C = e->C, Hd = e->Hd;
+    float* g = e->buf.grads;
+    const float* pf = e->buf.params;
+    const bf16* wt = (const bf16*)e->buf.params_bf16_t;
+    const bool dp_on = e->last_dropout && e->cfg.drop_path_rate > 0.f;
+    const float* dp1 = dp_on ? e->dp_scales + (size_t)(2 * l) * e->B : nullptr;
+    const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * e->B : nullptr;
+    const float pdrop = e->last_dropout ? e->cfg.attn_drop_rate : 0.f;
+    // --- MLP branch: x_out = x_mid + dp2 * gamma2 * (fc2(gelu(fc1(ln2(x_mid)))))
+    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, e->dY, g + o.g2, g + o.fc2b, M, C, e->N, s));
+    CHECK(uvit_gemm_tn_launch(e->dY, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, s));
+    GemmEpi d1; d1.out = e->dH; d1.aux = a.h; d1.ldo = Hd;
+    CHECK(uvit_gemm_nt_launch(EPI_DGELU, e->dY, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
+    CHECK(uvit_colsum_launch(e->dH, Hd, 0, Hd, M, g + o.fc1b, s));
+    CHECK(uvit_gemm_tn_launch(e->dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, s));
+    GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, g + o.n2w, g + o.n2b, M, C, s));
+    // --- attention branch: x_mid = x_in + dp1 * gamma1 * proj(attn(ln1(x_in)))
+    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, e->dY, g + o.g1, g + o.projb, M, C, e->N, s));
+    CHECK(uvit_gemm_tn_launch(e->dY, a.attn, Mp, C, C, C, C, g + o.projw, C, s));
+    GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dY, wt + o.projw, M, C, C, C, C, &d3, s));
+    const float* biasP = e->cfg.use_shared_rel_pos_bias ? e->biasP_s : nullptr;
+    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, e->dqkv, biasP ? e->slabs : nullptr,
+                               e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed,
+                               (uint32_t)l, s));
+    e->slab_started = true;
+    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 0, C, M, g + o.qb, s));
+    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 2 * C, C, M, g + o.vb, s));
+    CHECK(uvit_gemm_tn_launch(e->dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, s));
+    GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, g + o.n1w, g + o.n1b, M, C, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
+    if (!e) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Layout& lo = e->lo;
+    float* g = e->buf.grads;
+    const int C = e->C, BP = e->BP;
+    // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
+    CHECK(uvit_token_bwd_launch(e->dXa, e->mask_copy, e->dpatch, g + lo.cls, g + lo.mask_tok, e->B, e->P, C, s));
+    CHECK(uvit_colsum_launch(e->dpatch, C, 0, C, BP, g + lo.peb, s));
+    CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, s));
+    if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
+        CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream stream) {
+    if (!e || !hp) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Layout& lo = e->lo;
+    HIPCHECK(hipMemsetAsync(e->sumsq, 0, sizeof(double), s));
+    CHECK(uvit_sumsq_launch(e->buf.grads, lo.n_total, e->sumsq, s));
+    const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
+    CHECK(uvit_adamw_launch(e->buf.params, e->buf.grads, e->buf.adam_m, e->buf.adam_v, e->buf.params_bf16, lo.n_total, lo.n_decay,
+                            hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
+                            e->gnorm, s));
+    CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
+    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_total, hp->ema_decay, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
+                               uvit_stream stream) {
+    CHECK(uvit_step_begin(e, images, mask, hp, stream));
+    for (int l = e->cfg.depth - 1; l >= 0; --l) CHECK(uvit_step_backward_layer(e, l, hp, stream));
+    CHECK(uvit_step_backward_embed(e, stream));
+    return uvit_step_update(e, hp, stream);
+}
+
+extern "C" int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_stream stream) {
+    if (!e || !host_out2) return UVIT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(hipMemcpyAsync(host_out2, e->loss, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    return UVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// operator-level C ABI (thin wrappers over the internal launchers)
+// ------------------------------------------------------------------------------------------
+#define S(x) ((hipStream_t)(x))
+extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                               const uvit_gemm_epilogue* ep, uvit_stream st) {
+    if (!A || !W || !ep || !ep->out) return UVIT_ERR_ARG;
+    GemmEpi g; g.out = ep->out; g.out2 = ep->out2; g.bias = ep->bias; g.bias2 = ep->bias2; g.gamma = ep->gamma;
+    g.resid = ep->resid; g.rowscale = ep->rowscale; g.aux = ep->aux; g.mask = ep->mask; g.mask_token = ep->mask_token;
+    g.ldo = ep->ldo; g.tokens = ep->tokens > 0 ? ep->tokens : 1; g.patches = ep->patches > 0 ? ep->patches : 1;
+    return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st));
+}
+extern "C" int uvit_op_gemm_tn(const void* Y, const void* X, int M, int N, int K, int ldy, int ldx, float* C, int ldc, uvit_stream st) {
+    if (!Y || !X || !C) return UVIT_ERR_ARG;
+    return uvit_gemm_tn_launch(Y, X, M, N, K, ldy, ldx, C, ldc, S(st));
+}
+extern "C" int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
+                                float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
+    if (!qkv || !out || !lse) return UVIT_ERR_ARG;
+    return uvit_attn_fwd_launch(qkv, biasP, out, lse, B, H, N, NP, scale, p_drop, seed, layer, S(st));
+}
+extern "C" int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+                                float* delta, void* dqkv, float* slab, int acc, int chunk, int B, int H, int N, int NP,
+                                float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
+    if (!qkv || !o_fwd || !d_o || !lse || !delta || !dqkv) return UVIT_ERR_ARG;
+    return uvit_attn_bwd_launch(qkv, o_fwd, d_o, biasP, lse, delta, dqkv, slab, acc, chunk, B, H, N, NP, scale, p_drop, seed, layer, S(st));
+}
+extern "C" int uvit_op_relpos_gather(const float* t, const int32_t* idx, float* biasP, int H, int N, int NP, uvit_stream st) {
+    return uvit_relpos_gather_launch(t, idx, biasP, H, N, NP, S(st));
+}
+extern "C" int uvit_op_relpos_scatter(const float* slab, int nslab, const int32_t* idx, float* dt, int H, int N, int NP, uvit_stream st) {
+    return uvit_relpos_scatter_launch(slab, nslab, idx, dt, H, N, NP, S(st));
+}
+extern "C" int uvit_op_ln_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd, int M, int C,
+                              float eps, uvit_stream st) { return uvit_ln_fwd_launch(x, w, b, y, mean, rstd, M, C, eps, S(st)); }
+extern "C" int uvit_op_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                              const float* dres, float* dx, float* dw, float* db, int M, int C, uvit_stream st) {
+    return uvit_ln_bwd_launch(dy, x, mean, rstd, w, dres, dx, dw, db, M, C, S(st));
+}
+extern "C" int uvit_op_ema(float* ema, const float* p, void* eb, int64_t n, float d, uvit_stream st) {
+    return uvit_ema_launch(ema, p, eb, (size_t)n, d, S(st));
+}
+extern "C" int uvit_op_sumsq(const float* g, int64_t n, double* out, uvit_stream st) { return uvit_sumsq_launch(g, (size_t)n, out, S(st)); }
+extern "C" int uvit_op_adamw(float* p, const float* g, float* m, float* v, void* pb, int64_t n, int64_t nd, float lr, float wd,
+                             float b1, float b2, float eps, int step, const double* sumsq, float max_norm, float gs,
+                             float* gn, uvit_stream st) {
+    return uvit_adamw_launch(p, g, m, v, pb, (size_t)n, (size_t)nd, lr, wd, b1, b2, eps, step, sumsq, max_norm, gs, gn, S(st));
+}
+extern "C" int uvit_op_smooth_l1(const float* out, const float* target, const int32_t* count, float beta, int l2, float ls,
+                                 float* loss, void* dout, int Mmax, int C, uvit_stream st) {
+    return uvit_smooth_l1_launch(out, target, count, beta, l2, ls, loss, dout, Mmax, C, S(st));
+}
+extern "C" int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
+                                    int C, float eps, uvit_stream st) {
+    return uvit_target_accum_launch(x, rowidx, count, acc, first, Mmax, C, eps, S(st));
+}
+extern "C" int uvit_op_target_finalize(float* acc, const int32_t* count, int nl, int post_ln, int Mmax, int C, float eps, uvit_stream st) {
+    return uvit_target_finalize_launch(acc, count, nl, post_ln, Mmax, C, eps, S(st));
+}
+extern "C" int uvit_op_mask_compact(const int64_t* mask, int32_t* rowidx, int32_t* count, int B, int P, uvit_stream st) {
+    return uvit_mask_compact_launch(mask, rowidx, count, B, P, S(st));
+}
+extern "C" int uvit_op_im2col(const float* img, void* cols, int B, int Cin, int S_, int p, uvit_stream st) {
+    return uvit_im2col_launch(img, cols, B, Cin, S_, p, S(st));
+}
+extern "C" int uvit_op_droppath(float* sc, const float* rates, int depth, int B, uint32_t seed, uint32_t step, uvit_stream st) {
+    return uvit_droppath_launch(sc, rates, depth, B, seed, step, S(st));
+}
+extern "C" int uvit_op_cast_bf16(const float* src, void* dst, int64_t n, uvit_stream st) { return uvit_cast_bf16_launch(src, dst, (size_t)n, S(st)); }

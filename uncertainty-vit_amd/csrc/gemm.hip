@@ -1,0 +1,326 @@
+// bf16 MFMA GEMMs for the ViT step, gfx950.
+//
+//   NT :  C[M,N]  = A[M,K] . W[N,K]^T          (forward Linear, and dgrad with a W^T copy)
+//   TN :  C[N,K]  = dY[M,N]^T . X[M,K]         (wgrad; reduction over the token dimension)
+//
+// Both use a 128x128 block tile, BK = 64, 4 waves (2x2) of 64x64 each, 16x16x32 bf16 MFMA with
+// fp32 accumulation, operands staged HBM -> LDS with global_load_lds (16 B/lane, no VGPR round
+// trip), two LDS stages, XOR-swizzled so the fragment reads are bank-conflict free:
+//   NT  tiles are [rows][64 k]  (128-B rows), read with ds_read_b128;
+//   TN  tiles are [64 m][128 c] (256-B rows), read with ds_read_b64_tr_b16 (hardware transpose).
+// The MFMA is issued "swapped" (weight rows as the A operand) so that each lane ends up with 4
+// consecutive output columns of one output row -> 8/16-byte vector epilogue loads and stores.
+// Epilogues fuse bias, GELU, LayerScale*DropPath*residual, GELU', mask-token blend.
+#include "common.h"
+#include "uvit_internal.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GEMM_THREADS 256
+#define STAGE_BYTES (BM * BK * 2)   // 16 KiB per operand per stage
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(void, g), LDS_PTR(void, lds_wave_base), 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// epilogue: acc[j] holds C[m][n..n+3]
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n, int N, f32x4 acc) {
+    const size_t o = (size_t)m * e.ldo + n;
+    if constexpr (MODE == EPI_BF16 || MODE == EPI_F32 || MODE == EPI_QKV) {
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == EPI_QKV) {
+            // bias = cat(q_bias, 0, v_bias)  (modeling_finetune.py:149-151)
+            const int C = N / 3;
+            const float* src = n < C ? e.bias + n : (n >= 2 * C ? e.bias2 + (n - 2 * C) : nullptr);
+            if (src) { const float4 t = *(const float4*)src; b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w; }
+        } else if (e.bias) {
+            const float4 t = *(const float4*)(e.bias + n); b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+        }
+        if constexpr (MODE == EPI_F32) {
+            *(float4*)((float*)e.out + o) = make_float4(acc[0] + b[0], acc[1] + b[1], acc[2] + b[2], acc[3] + b[3]);
+        } else {
+            bf16x4 v = {f2bf(acc[0] + b[0]), f2bf(acc[1] + b[1]), f2bf(acc[2] + b[2]), f2bf(acc[3] + b[3])};
+            *(bf16x4*)((bf16*)e.out + o) = v;
+        }
+    } else if constexpr (MODE == EPI_GELU) {
+        const float4 t = *(const float4*)(e.bias + n);
+        const float h0 = acc[0] + t.x, h1 = acc[1] + t.y, h2 = acc[2] + t.z, h3 = acc[3] + t.w;
+        // pre-activation is kept in bf16 for backward; GELU is evaluated on the rounded value so
+        // forward and backward see the same h
+        bf16x4 hv = {f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
+        if (e.out2) *(bf16x4*)((bf16*)e.out2 + o) = hv;
+        bf16x4 av = {f2bf(gelu_exact(bf2f(hv[0]))), f2bf(gelu_exact(bf2f(hv[1]))),
+                     f2bf(gelu_exact(bf2f(hv[2]))), f2bf(gelu_exact(bf2f(hv[3])))};
+        *(bf16x4*)((bf16*)e.out + o) = av;
+    } else if constexpr (MODE == EPI_RESID) {
+        // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
+        const float4 t = *(const float4*)(e.bias + n);
+        const float4 g = *(const float4*)(e.gamma + n);
+        const float4 r = *(const float4*)(e.resid + o);
+        const float dp = e.rowscale ? e.rowscale[m / e.tokens] : 1.0f;
+        const float y0 = acc[0] + t.x, y1 = acc[1] + t.y, y2 = acc[2] + t.z, y3 = acc[3] + t.w;
+        if (e.out2) {
+            bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
+            *(bf16x4*)((bf16*)e.out2 + o) = yv;
+        }
+        *(float4*)((float*)e.out + o) = make_float4(r.x + dp * g.x * y0, r.y + dp * g.y * y1,
+                                                    r.z + dp * g.z * y2, r.w + dp * g.w * y3);
+    } else if constexpr (MODE == EPI_PATCH) {
+        // row m = b*P + p of the patch GEMM lands in token row b*(P+1) + 1 + p; masked patches take
+        // the mask token (modeling_cyclical.py:179-182)
+        const int b = m / e.patches, p = m - b * e.patches;
+        const size_t orow = (size_t)(b * (e.patches + 1) + 1 + p) * e.ldo + n;
+        const bool masked = e.mask && e.mask[m] != 0;
+        const float4 t = masked ? *(const float4*)(e.mask_token + n) : *(const float4*)(e.bias + n);
+        float4 v;
+        if (masked) v = t;
+        else v = make_float4(acc[0] + t.x, acc[1] + t.y, acc[2] + t.z, acc[3] + t.w);
+        *(float4*)((float*)e.out + orow) = v;
+    } else if constexpr (MODE == EPI_DGELU) {
+        const bf16x4 h = *(const bf16x4*)((const bf16*)e.aux + o);
+        bf16x4 v = {f2bf(acc[0] * gelu_grad(bf2f(h[0]))), f2bf(acc[1] * gelu_grad(bf2f(h[1]))),
+                    f2bf(acc[2] * gelu_grad(bf2f(h[2]))), f2bf(acc[3] * gelu_grad(bf2f(h[3])))};
+        *(bf16x4*)((bf16*)e.out + o) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
+                    int lda, int ldw, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 16K | W 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    // consecutive ids walk N first so one XCD's chunk shares the A panel
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    // staging: wave-instruction ii (0..15) fills rows ii*8..ii*8+7; lane -> (row, phys chunk)
+    const int srow = lane >> 3, pchunk = lane & 7;
+    const int schunk = pchunk ^ srow;                 // source chunk (swizzle on the SOURCE side)
+    const bf16* a_src[4];
+    const bf16* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 8 + srow;
+        int ar = m0 + row; ar = ar < M ? ar : M - 1;
+        int br = n0 + row; br = br < N ? br : N - 1;
+        a_src[i] = A + (size_t)ar * lda + schunk * 8;
+        w_src[i] = W + (size_t)br * ldw + schunk * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * (2 * STAGE_BYTES);
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = i * 4 + wave;
+            glds16(a_src[i] + k0, base + ii * 1024);
+            glds16(w_src[i] + k0, base + STAGE_BYTES + ii * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * (2 * STAGE_BYTES);
+        const char* sw = sa + STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], wf[4];
+            const int chunk = kk * 4 + g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra = wr * 64 + t * 16 + li;
+                af[t] = *(const bf16x8*)(sa + ra * 128 + ((chunk ^ (ra & 7)) << 4));
+                const int rw = wc * 64 + t * 16 + li;
+                wf[t] = *(const bf16x8*)(sw + rw * 128 + ((chunk ^ (rw & 7)) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // D layout (swapped operands): lane col (li) = m_local, rows 4g+r = n_local
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 64 + mt * 16 + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+            if (n < N) epilogue4<MODE>(epi, m, n, N, acc[mt][nt]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN kernel:  C[Nn,Kk] = Y[M,Nn]^T . X[M,Kk];  M (reduction) must be a multiple of 64 and the
+// buffers readable (zero rows) up to it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int kk, int lane) {
+    // operand element j of lane (g, i): tile[row = kk*32 + 8g + j][col0 + i]
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
+    const int chunk = (col0 >> 3) + (p >> 1);
+    const int a0 = r0 * 256 + ((chunk ^ tn_swz(r0)) << 4) + ((p & 1) << 3);
+    const int a1 = r1 * 256 + ((chunk ^ tn_swz(r1)) << 4) + ((p & 1) << 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2)
+void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int M, int Nn, int Kk,
+                    int ldy, int ldx, float* __restrict__ C, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Y tile 16K | X tile 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_k = (Kk + BN - 1) / BN, tiles_n = (Nn + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_n * tiles_k);
+    const int tn = bid / tiles_k, tk = bid - tn * tiles_k;
+    const int n0 = tn * BM, k0 = tk * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    // staging: wave-instruction ii (0..15) fills tile rows ii*4..ii*4+3 (256-B rows)
+    const int srow = lane >> 4, pchunk = lane & 15;
+    const bf16* y_src[4];
+    const bf16* x_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 4 + srow;
+        const int sch = pchunk ^ tn_swz(row);
+        int yc = n0 / 8 + sch; yc = yc < Nn / 8 ? yc : Nn / 8 - 1;
+        int xc = k0 / 8 + sch; xc = xc < Kk / 8 ? xc : Kk / 8 - 1;
+        y_src[i] = Y + (size_t)row * ldy + yc * 8;
+        x_src[i] = X + (size_t)row * ldx + xc * 8;
+    }
+    auto stage = [&](int buf, int mt) {
+        char* base = smem + buf * (2 * STAGE_BYTES);
+        const size_t mrow = (size_t)mt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = i * 4 + wave;
+            glds16(y_src[i] + mrow * ldy, base + ii * 1024);
+            glds16(x_src[i] + mrow * ldx, base + STAGE_BYTES + ii * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nm = M / BK;
+    stage(0, 0);
+    for (int mt = 0; mt < nm; ++mt) {
+        const int cur = mt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (mt + 1 < nm) stage(cur ^ 1, mt + 1);
+        const char* sy = smem + cur * (2 * STAGE_BYTES);
+        const char* sx = sy + STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 yf[4], xf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                yf[t] = tr_frag(sy, wr * 64 + t * 16, kk, lane);
+                xf[t] = tr_frag(sx, wc * 64 + t * 16, kk, lane);
+            }
+            // D[i = k_local][j = n_local] = sum_m X[m][k] Y[m][n]
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kt], yf[nt], acc[nt][kt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wr * 64 + nt * 16 + li;
+        if (n >= Nn) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wc * 64 + kt * 16 + 4 * g;
+            if (k < Kk) {
+                const f32x4 a = acc[nt][kt];
+                *(float4*)(C + (size_t)n * ldc + k) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+static bool g_attr_done = false;
+template <typename F>
+static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
+
+static void gemm_init_once() {
+    if (g_attr_done) return;
+    allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
+    allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
+    allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_tn_kernel);
+    g_attr_done = true;
+}
+
+int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                        const GemmEpi* epi, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
+        return UVIT_ERR_SHAPE;
+    gemm_init_once();
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const size_t lds = 4 * STAGE_BYTES;
+    const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
+#define L(MODE) hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi)
+    switch (mode) {
+        case EPI_BF16: L(EPI_BF16); break;
+        case EPI_QKV: if (N % 3) return UVIT_ERR_SHAPE; L(EPI_QKV); break;
+        case EPI_GELU: L(EPI_GELU); break;
+        case EPI_RESID: L(EPI_RESID); break;
+        case EPI_F32: L(EPI_F32); break;
+        case EPI_PATCH: L(EPI_PATCH); break;
+        case EPI_DGELU: L(EPI_DGELU); break;
+        default: return UVIT_ERR_ARG;
+    }
+#undef L
+    return uvit_check_launch();
+}
+
+int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
+                        int ldc, hipStream_t s) {
+    if (M <= 0 || (M % BK) || (Nn % 8) || (Kk % 8) || (ldy % 8) || (ldx % 8) || (ldc % 4)) return UVIT_ERR_SHAPE;
+    gemm_init_once();
+    const int grid = ((Nn + BM - 1) / BM) * ((Kk + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(GEMM_THREADS), 4 * STAGE_BYTES, s, (const bf16*)Y,
+                       (const bf16*)X, M, Nn, Kk, ldy, ldx, C, ldc);
+    return uvit_check_launch();
+}

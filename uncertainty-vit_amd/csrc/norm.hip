@@ -1,0 +1,259 @@
+// LayerNorm forward/backward and the data2vec target builder, gfx950.  HBM-bound: one wave per
+// row, float4 loads of the fp32 residual stream, row statistics by wave shuffles, bf16x4 stores.
+//
+// Reference: nn.LayerNorm(eps=1e-6) inside Block (modeling_finetune.py:290-299); target builder
+// = affine-free F.layer_norm(eps=1e-5) per layer, mean over layers, optional post layer_norm,
+// masked-row gather (engine_for_cyclical.py:92-122).
+#include "common.h"
+#include "uvit_internal.h"
+
+#define LN_MAXV 8          // float4 per lane: C <= 2048
+#define LN_WAVES 4
+
+struct RowVec { float4 v[LN_MAXV]; };
+
+__device__ __forceinline__ void load_row(RowVec& r, const float* x, int C, int lane) {
+    const int nv = C >> 2;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int i = lane + 64 * k;
+        r.v[k] = i < nv ? ((const float4*)x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void row_stats(const RowVec& r, int C, int lane, float eps, float& mean, float& rstd) {
+    const int nv = C >> 2;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) s += r.v[k].x + r.v[k].y + r.v[k].z + r.v[k].w;
+    mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        if (lane + 64 * k < nv) {
+            const float a = r.v[k].x - mean, b = r.v[k].y - mean, c = r.v[k].z - mean, d = r.v[k].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / C + eps);
+}
+
+// y = (x - mean) * rstd * w + b  ->  bf16
+__global__ __launch_bounds__(LN_WAVES * 64)
+void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, const int* __restrict__ count,
+                   const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ y,
+                   float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    const int n_valid = count ? *count : M;
+    if (row >= n_valid) {     // padded compact rows stay zero
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) ((bf16x4*)(y + (size_t)row * C))[i] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        }
+        return;
+    }
+    const int src = rowidx ? rowidx[row] : row;
+    RowVec r;
+    load_row(r, x + (size_t)src * C, C, lane);
+    float mean, rstd;
+    row_stats(r, C, lane, eps, mean, rstd);
+    if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            const float4 ww = ((const float4*)w)[i], bb = ((const float4*)b)[i];
+            bf16x4 o = {f2bf((r.v[k].x - mean) * rstd * ww.x + bb.x), f2bf((r.v[k].y - mean) * rstd * ww.y + bb.y),
+                        f2bf((r.v[k].z - mean) * rstd * ww.z + bb.z), f2bf((r.v[k].w - mean) * rstd * ww.w + bb.w)};
+            ((bf16x4*)(y + (size_t)row * C))[i] = o;
+        }
+    }
+}
+
+// dx = dres + rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += dy*xhat;  db += dy
+#define LNB_ROWS 32   // rows per block
+__global__ __launch_bounds__(LN_WAVES * 64)
+void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ rowidx,
+                   const int* __restrict__ count, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                   const float* __restrict__ w, const float* __restrict__ dres, float* __restrict__ dx,
+                   float* __restrict__ dw, float* __restrict__ db, int M, int C) {
+    __shared__ float red[2][LN_WAVES][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    const int n_valid = count ? min(*count, M) : M;
+    RowVec aw, ab;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
+    const int row_end = min((int)(blockIdx.x + 1) * LNB_ROWS, n_valid);
+    for (int row = blockIdx.x * LNB_ROWS + wave; row < row_end; row += LN_WAVES) {
+        const int xr = rowidx ? rowidx[row] : row;
+        RowVec r;
+        load_row(r, x + (size_t)xr * C, C, lane);
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float4 g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) {
+                const bf16x4 d = ((const bf16x4*)(dy + (size_t)row * C))[i];
+                const float4 ww = ((const float4*)w)[i];
+                const float d0 = bf2f(d[0]), d1 = bf2f(d[1]), d2 = bf2f(d[2]), d3 = bf2f(d[3]);
+                const float h0 = (r.v[k].x - mean) * rstd, h1 = (r.v[k].y - mean) * rstd,
+                            h2 = (r.v[k].z - mean) * rstd, h3 = (r.v[k].w - mean) * rstd;
+                aw.v[k].x += d0 * h0; aw.v[k].y += d1 * h1; aw.v[k].z += d2 * h2; aw.v[k].w += d3 * h3;
+                ab.v[k].x += d0; ab.v[k].y += d1; ab.v[k].z += d2; ab.v[k].w += d3;
+                g[k] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
+                s1 += g[k].x + g[k].y + g[k].z + g[k].w;
+                s2 += g[k].x * h0 + g[k].y * h1 + g[k].z * h2 + g[k].w * h3;
+                r.v[k] = make_float4(h0, h1, h2, h3);
+            } else {
+                g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) {
+                float4 o = make_float4(rstd * (g[k].x - s1 - r.v[k].x * s2), rstd * (g[k].y - s1 - r.v[k].y * s2),
+                                       rstd * (g[k].z - s1 - r.v[k].z * s2), rstd * (g[k].w - s1 - r.v[k].w * s2));
+                if (dres) {
+                    const float4 d = ((const float4*)(dres + (size_t)xr * C))[i];
+                    o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+                }
+                ((float4*)(dx + (size_t)xr * C))[i] = o;
+            }
+        }
+    }
+    // cross-wave reduction of the column partials, then one atomic per column per block
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        if (64 * k < nv) {
+            __syncthreads();
+            ((float4*)red[0][wave])[lane] = aw.v[k];
+            ((float4*)red[1][wave])[lane] = ab.v[k];
+            __syncthreads();
+            if (wave == 0) {
+                float4 sw = ((float4*)red[0][0])[lane], sb = ((float4*)red[1][0])[lane];
+#pragma unroll
+                for (int q = 1; q < LN_WAVES; ++q) {
+                    const float4 a = ((float4*)red[0][q])[lane], c = ((float4*)red[1][q])[lane];
+                    sw.x += a.x; sw.y += a.y; sw.z += a.z; sw.w += a.w;
+                    sb.x += c.x; sb.y += c.y; sb.z += c.z; sb.w += c.w;
+                }
+                const int i = lane + 64 * k;
+                if (i < nv) {
+                    atomicAdd(dw + 4 * i + 0, sw.x); atomicAdd(dw + 4 * i + 1, sw.y);
+                    atomicAdd(dw + 4 * i + 2, sw.z); atomicAdd(dw + 4 * i + 3, sw.w);
+                    atomicAdd(db + 4 * i + 0, sb.x); atomicAdd(db + 4 * i + 1, sb.y);
+                    atomicAdd(db + 4 * i + 2, sb.z); atomicAdd(db + 4 * i + 3, sb.w);
+                }
+            }
+        }
+    }
+}
+
+// acc[i] (+)= layer_norm(x[rowidx[i]])  (no affine)
+__global__ __launch_bounds__(LN_WAVES * 64)
+void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, const int* __restrict__ count,
+                         float* __restrict__ acc, int first, int Mmax, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= Mmax) return;
+    const int nv = C >> 2;
+    float4* dst = (float4*)(acc + (size_t)row * C);
+    if (row >= *count) {
+        if (first)
+#pragma unroll
+            for (int k = 0; k < LN_MAXV; ++k) if (lane + 64 * k < nv) dst[lane + 64 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    RowVec r;
+    load_row(r, x + (size_t)rowidx[row] * C, C, lane);
+    float mean, rstd;
+    row_stats(r, C, lane, eps, mean, rstd);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            float4 o = make_float4((r.v[k].x - mean) * rstd, (r.v[k].y - mean) * rstd, (r.v[k].z - mean) * rstd,
+                                   (r.v[k].w - mean) * rstd);
+            if (!first) { const float4 a = dst[i]; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+            dst[i] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(LN_WAVES * 64)
+void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ count, float inv_layers, int post_ln,
+                            int Mmax, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= Mmax || row >= *count) return;
+    const int nv = C >> 2;
+    RowVec r;
+    load_row(r, acc + (size_t)row * C, C, lane);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) { r.v[k].x *= inv_layers; r.v[k].y *= inv_layers; r.v[k].z *= inv_layers; r.v[k].w *= inv_layers; }
+    float mean = 0.f, rstd = 1.f;
+    if (post_ln) row_stats(r, C, lane, eps, mean, rstd);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv)
+            ((float4*)(acc + (size_t)row * C))[i] = make_float4((r.v[k].x - mean) * rstd, (r.v[k].y - mean) * rstd,
+                                                                 (r.v[k].z - mean) * rstd, (r.v[k].w - mean) * rstd);
+    }
+}
+
+static int ln_shape_ok(int M, int C) { return (M > 0 && C > 0 && (C % 4) == 0 && C <= LN_MAXV * 256) ? UVIT_OK : UVIT_ERR_SHAPE; }
+
+int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd, int M, int C,
+                       float eps, hipStream_t s) {
+    if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, (const int*)nullptr,
+                       (const int*)nullptr, w, b, (bf16*)y, mean, rstd, M, C, eps);
+    return uvit_check_launch();
+}
+int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* count, const float* w, const float* b,
+                              void* y, float* mean, float* rstd, int Mmax, int C, float eps, hipStream_t s) {
+    if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx, count,
+                       w, b, (bf16*)y, mean, rstd, Mmax, C, eps);
+    return uvit_check_launch();
+}
+int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* dres, float* dx, float* dw, float* db, int M, int C, hipStream_t s) {
+    if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C);
+    return uvit_check_launch();
+}
+int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,
+                               const float* rstd, const float* w, float* dx, float* dw, float* db, int Mmax, int C,
+                               hipStream_t s) {
+    if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C);
+    return uvit_check_launch();
+}
+int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
+                             int C, float eps, hipStream_t s) {
+    if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(target_accum_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx,
+                       count, acc, first, Mmax, C, eps);
+    return uvit_check_launch();
+}
+int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
+                                hipStream_t s) {
+    if (ln_shape_ok(Mmax, C) || n_layers <= 0) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(target_finalize_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, acc,
+                       count, 1.0f / n_layers, post_ln, Mmax, C, eps);
+    return uvit_check_launch();
+}

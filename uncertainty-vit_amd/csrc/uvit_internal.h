@@ -1,0 +1,78 @@
+// Internal launch interfaces shared by the .hip translation units of libuvit (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { EPI_BF16 = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_PATCH = 5, EPI_DGELU = 6 };
+
+struct GemmEpi {
+    void* out = nullptr;             // bf16 or f32 [M, ldo]
+    void* out2 = nullptr;            // GELU: pre-activation h (bf16); RESID: branch output before gamma (bf16)
+    const float* bias = nullptr;     // [N]   (QKV: q_bias [N/3])
+    const float* bias2 = nullptr;    // QKV: v_bias [N/3]
+    const float* gamma = nullptr;    // RESID: LayerScale [N]
+    const float* resid = nullptr;    // RESID: residual stream [M, ldo] f32
+    const float* rowscale = nullptr; // RESID: per-sample drop-path multiplier [B] (null = 1)
+    const void* aux = nullptr;       // DGELU: h [M, ldo] bf16
+    const int64_t* mask = nullptr;   // PATCH: bool_masked_pos flattened [B*P] (null = teacher)
+    const float* mask_token = nullptr;
+    int ldo = 0;
+    int tokens = 1;                  // RESID: rows per sample
+    int patches = 1;                 // PATCH: rows per sample in the GEMM
+};
+
+// gemm.hip
+int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                        const GemmEpi* epi, hipStream_t s);
+int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
+                        int ldc, hipStream_t s);
+
+// attention.hip
+int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
+                         float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+                         float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H,
+                         int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+
+// norm.hip
+int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y_bf16, float* mean, float* rstd,
+                       int M, int C, float eps, hipStream_t s);
+int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* count, const float* w, const float* b,
+                              void* y_bf16, float* mean, float* rstd, int Mmax, int C, float eps, hipStream_t s);
+int uvit_ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* dres, float* dx, float* dw, float* db, int M, int C, hipStream_t s);
+int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* rowidx, const int* count,
+                               const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
+                               int Mmax, int C, hipStream_t s);
+int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
+                             int C, float eps, hipStream_t s);
+int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
+                                hipStream_t s);
+
+// elementwise.hip
+int uvit_im2col_launch(const float* img, void* cols_bf16, int B, int Cin, int img_size, int patch, hipStream_t s);
+int uvit_mask_compact_launch(const int64_t* mask, int* rowidx, int* count, int B, int P, hipStream_t s);
+int uvit_set_cls_launch(float* x, const float* cls, const float* pos, int B, int N, int C, hipStream_t s);
+int uvit_relpos_gather_launch(const float* table, const int* index, float* biasP, int H, int N, int NP, hipStream_t s);
+int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, float* dtable, int H, int N, int NP,
+                               hipStream_t s);
+int uvit_ls_bwd_launch(const float* dx, const void* branch_bf16, const float* gamma, const float* rowscale,
+                       void* dy_bf16, float* dgamma, float* dbias, int M, int C, int tokens, hipStream_t s);
+int uvit_colsum_launch(const void* y_bf16, int ld, int col0, int ncols, int M, float* out, hipStream_t s);
+int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,
+                          float* loss, void* dout_bf16, int Mmax, int C, hipStream_t s);
+int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf16, float* dcls, float* dmask_token,
+                          int B, int P, int C, hipStream_t s);
+int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
+int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step,
+                         hipStream_t s);
+
+// optim.hip
+int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s);
+int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s);
+int uvit_adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, size_t n_decay, float lr,
+                      float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
+                      float grad_scale, float* gnorm_out, hipStream_t s);
+int uvit_cast_bf16_launch(const float* src, void* dst_bf16, size_t n, hipStream_t s);
+
+struct TransposeDesc { const void* src; void* dst; int rows; int cols; int tile0; int pad; };

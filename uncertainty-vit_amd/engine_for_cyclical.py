@@ -1,0 +1,217 @@
+"""train_one_epoch with the reference's signature and meter names (engine_for_cyclical.py:24-227);
+each iteration runs as hand-written HIP kernels through libuvit:
+
+    teacher forward (EMA weights) -> targets -> student forward -> SmoothL1 -> backward
+    -> [RCCL all-reduce of the gradient arena, bucketed per block, overlapped with backward]
+    -> global-norm clip + AdamW -> EMA
+
+Data parallelism: one process per GPU; gradients are averaged with torch.distributed
+(`nccl` = RCCL over xGMI) on a side stream while the compute stream keeps running backward.
+"""
+import ctypes as C
+import math
+import sys
+from typing import Iterable
+
+import torch
+import torch.distributed as dist
+
+from . import utils
+from .native import StepParams, check, cur_stream, lib, ptr
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") and not hasattr(model, "_arena") else model
+
+
+class GradReducer:
+    """Bucketed all-reduce(SUM) of the flat gradient arena, launched as soon as a block's
+    gradients are final (the reference gets this from DDP hooks, run_cyclical.py:515-519)."""
+
+    def __init__(self, model, enabled):
+        self.enabled = enabled and utils.get_world_size() > 1
+        if not self.enabled:
+            return
+        self.world = utils.get_world_size()
+        self.on_gpu = model._arena.is_cuda
+        self.comm = torch.cuda.Stream() if self.on_gpu else None
+        lay = {n: (o, k) for n, o, k, _, _ in model._layout}
+        d = model.depth
+        self.layer_ranges = []
+        for i in range(d):
+            lo = lay[f"blocks.{i}.attn.qkv.weight"][0]
+            hi = sum(lay[f"blocks.{i}.mlp.fc2.weight"])
+            self.layer_ranges.append((lo, hi))
+        self.head_range = (lay["lm_head.weight"][0], sum(lay["lm_head.weight"]))
+        self.embed_range = (0, lay["blocks.0.attn.qkv.weight"][0])
+        self.small_range = (model._n_decay, model._arena.numel())      # every no-decay tensor, one message
+        self.pending = []
+
+    def reduce(self, grads, rng):
+        if not self.enabled or rng[1] <= rng[0]:
+            return
+        view = grads[rng[0]:rng[1]]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm.wait_event(ev)
+            with torch.cuda.stream(self.comm):
+                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        if not self.enabled:
+            return
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
+def native_step(engine, reducer, samples, mask, hp):
+    """One training iteration on the current stream; returns nothing (stats stay on the device)."""
+    L, h, s = lib(), engine.h, cur_stream()
+    hp_ref = C.byref(hp)
+    if reducer is None or not reducer.enabled:
+        check(L.uvit_train_step(h, ptr(samples), ptr(mask), hp_ref, s), "uvit_train_step")
+        return
+    g = engine.grads
+    check(L.uvit_step_begin(h, ptr(samples), ptr(mask), hp_ref, s), "uvit_step_begin")
+    reducer.reduce(g, reducer.head_range)
+    for l in range(engine.model.depth - 1, -1, -1):
+        check(L.uvit_step_backward_layer(h, l, hp_ref, s), "uvit_step_backward_layer")
+        reducer.reduce(g, reducer.layer_ranges[l])
+    check(L.uvit_step_backward_embed(h, s), "uvit_step_backward_embed")
+    reducer.reduce(g, reducer.embed_range)
+    reducer.reduce(g, reducer.small_range)
+    reducer.finish()
+    check(L.uvit_step_update(h, hp_ref, s), "uvit_step_update")
+
+
+def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
+                     post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True):
+    hp = StepParams()
+    for i, t in enumerate(target_layers):
+        hp.target_layers[i] = int(t)
+    hp.n_target_layers = len(target_layers)
+    hp.target_layer_norm_last = int(bool(target_layer_norm_last))
+    hp.post_target_layer_norm = int(bool(post_target_layer_norm))
+    hp.l2_loss = int(bool(l2_loss))
+    hp.l1_beta, hp.loss_scale = float(l1_beta), float(loss_scale)
+    hp.clip_grad = float(max_norm) if max_norm else 0.0
+    g0 = optimizer.param_groups[0]
+    hp.lr, hp.weight_decay = float(g0["lr"]), float(g0["weight_decay"])
+    hp.beta1, hp.beta2, hp.eps = float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"])
+    hp.opt_step = optimizer.step_count + 1
+    hp.ema_decay, hp.do_ema = float(cur_decay), int(bool(do_ema))
+    hp.grad_scale = 1.0 / world
+    hp.seed, hp.it = int(seed) & 0xFFFFFFFF, int(it) & 0xFFFFFFFF
+    hp.train_dropout = int(bool(train_dropout))
+    return hp
+
+
+def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_start_at, decay_init, decay, target_layers,
+                    data_loader: Iterable, optimizer, device: torch.device, epoch: int, loss_scaler,
+                    max_norm: float = 0, l1_beta: float = 0.12, log_writer=None, lr_scheduler=None, start_steps=None,
+                    lr_schedule_values=None, wd_schedule_values=None, l2_loss=False, layer_results='end',
+                    var_w0=0, var_w1=0, var_margin0=0.5, var_margin1=0.5, start_lr_decay_at_step=-1, loss_scale=-1,
+                    mask_dropout_prob=-1.0, target_layer_norm_last=True, target_batch_norm=False,
+                    target_instance_norm=False, post_target_instance_norm=False, post_target_layer_norm=False,
+                    stochastic=False, lambda_pretraining=1e-5):
+    print(' <<<<<<<< layer_results >>>>>>>>', layer_results)
+    print(' <<<<<<<< var_w0, var_w1 >>>>>>>>', var_w0, var_w1)
+    # flags whose arithmetic is not on the configured hot path are refused, never approximated
+    if stochastic:
+        raise NotImplementedError("--stochastic selects the two-stream model (dist_beit_base_patch16_224); not built yet (DESIGN.md)")
+    if layer_results != 'end' or target_batch_norm or target_instance_norm or post_target_instance_norm or var_w0 > 0 \
+            or not target_layer_norm_last:
+        raise NotImplementedError("only layer_results='end' with target layer-norm (README.md:11-25 recipe) is native")
+    model.train()
+    net = _unwrap(model)
+    teacher = model_ema.module
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    metric_logger.add_meter('min_lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    metric_logger.add_meter('loss_var0', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    print_freq = 10
+    world = utils.get_world_size()
+    reducer = None
+    engine = None
+    stats = torch.zeros(2, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
+    seed = torch.initial_seed()
+
+    cur_decay = decay
+    for step, (batch, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+        it = start_steps + step  # global training iteration
+        # per-step lr / weight-decay (engine_for_cyclical.py:47-53)
+        if lr_schedule_values is not None or wd_schedule_values is not None:
+            for param_group in optimizer.param_groups:
+                if lr_schedule_values is not None:
+                    param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
+                if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                    param_group["weight_decay"] = wd_schedule_values[it]
+        if it < ema_start_at:
+            cur_decay = decay_init + it * (decay - decay_init) / ema_start_at
+
+        samples, bool_masked_pos = batch
+        samples = samples.to(device, non_blocking=True).float().contiguous()
+        bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
+        if mask_dropout_prob > 0:
+            keep = torch.bernoulli(torch.full_like(bool_masked_pos, 1 - mask_dropout_prob, dtype=samples.dtype))
+            bool_masked_pos = torch.logical_and(keep, bool_masked_pos)
+        mask = bool_masked_pos.reshape(samples.shape[0], -1).to(torch.int64).contiguous()
+
+        if engine is None:
+            optimizer._ensure_state()
+            engine = net.engine(samples.shape[0], teacher=teacher, adam_m=optimizer.exp_avg, adam_v=optimizer.exp_avg_sq)
+            reducer = GradReducer(net, world > 1)
+        if samples.shape[0] != engine.batch:
+            raise ValueError("the native step runs at the batch size the workspace was planned for (drop_last=True loader)")
+
+        do_ema = cur_decay != 1 and (start_lr_decay_at_step == -1 or it <= start_lr_decay_at_step)
+        if not do_ema:
+            cur_decay = 0
+        hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
+                              post_target_layer_norm, cur_decay, do_ema, world, seed, it)
+        native_step(engine, reducer, samples, mask, hp)
+        optimizer.step_count += 1
+
+        # one host sync per step, as the reference (loss.item() + torch.cuda.synchronize())
+        check(lib().uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "read_stats")
+        loss_value, grad_norm = float(stats[0]), float(stats[1])
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value), force=True) if world > 1 else \
+                print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        loss_scale_value = loss_scaler.state_dict()["scale"] if loss_scaler is not None else 1.0
+
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(loss_scale=loss_scale_value)
+        lrs = [g["lr"] for g in optimizer.param_groups]
+        metric_logger.update(lr=max(lrs))
+        metric_logger.update(min_lr=min(lrs))
+        metric_logger.update(loss_var0=0)
+        wds = [g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0]
+        weight_decay_value = wds[-1] if wds else None
+        metric_logger.update(weight_decay=weight_decay_value)
+        metric_logger.update(grad_norm=grad_norm)
+        metric_logger.update(cur_decay=cur_decay)
+
+        if log_writer is not None:
+            log_writer.update(loss=loss_value, head="loss")
+            log_writer.update(loss_scale=loss_scale_value, head="opt")
+            log_writer.update(lr=max(lrs), head="opt")
+            log_writer.update(min_lr=min(lrs), head="opt")
+            log_writer.update(weight_decay=weight_decay_value, head="opt")
+            log_writer.update(grad_norm=grad_norm, head="opt")
+            log_writer.update(cur_decay=cur_decay, head="cur_decay")
+            log_writer.set_step()
+        if lr_scheduler is not None:
+            lr_scheduler.step_update(start_steps + step)
+
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
