@@ -443,8 +443,8 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     const int Bc = e->B, BP = e->BP, C = e->C;
     Layout& lo = e->lo;
     // zero the accumulated (atomic) gradient ranges + step scalars
-    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.pew * sizeof(float), s));                       // mask_token, rel table
-    HIPCHECK(hipMemsetAsync(e->buf.grads + lo.n_decay, 0, (lo.n_total - lo.n_decay) * sizeof(float), s));
+    // every gradient is accumulated (split-K wgrad atomics, bias/LN/gamma column sums): zero the arena once
+    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), s));
     HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), s));
     e->slab_started = false;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -462,7 +462,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     float* g = e->buf.grads;
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
     CHECK(uvit_colsum_launch(e->dout, C, 0, C, BP, g + lo.lmb, s));
-    CHECK(uvit_gemm_tn_launch(e->dout, e->normed, e->BPpad, C, C, C, C, g + lo.lmw, C, s));
+    CHECK(uvit_gemm_tn_launch(e->dout, e->normed, e->BPpad, C, C, C, C, g + lo.lmw, C, 1, s));
     GemmEpi d; d.out = e->dnormed; d.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout, wt + lo.lmw, BP, C, C, C, C, &d, s));
     // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
@@ -488,17 +488,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     const float pdrop = e->last_dropout ? e->cfg.attn_drop_rate : 0.f;
     // --- MLP branch: x_out = x_mid + dp2 * gamma2 * (fc2(gelu(fc1(ln2(x_mid)))))
     CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, e->dY, g + o.g2, g + o.fc2b, M, C, e->N, s));
-    CHECK(uvit_gemm_tn_launch(e->dY, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, s));
+    CHECK(uvit_gemm_tn_launch(e->dY, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, 1, s));
     GemmEpi d1; d1.out = e->dH; d1.aux = a.h; d1.ldo = Hd;
     CHECK(uvit_gemm_nt_launch(EPI_DGELU, e->dY, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
     CHECK(uvit_colsum_launch(e->dH, Hd, 0, Hd, M, g + o.fc1b, s));
-    CHECK(uvit_gemm_tn_launch(e->dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, s));
+    CHECK(uvit_gemm_tn_launch(e->dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, 1, s));
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
     CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, g + o.n2w, g + o.n2b, M, C, s));
     // --- attention branch: x_mid = x_in + dp1 * gamma1 * proj(attn(ln1(x_in)))
     CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, e->dY, g + o.g1, g + o.projb, M, C, e->N, s));
-    CHECK(uvit_gemm_tn_launch(e->dY, a.attn, Mp, C, C, C, C, g + o.projw, C, s));
+    CHECK(uvit_gemm_tn_launch(e->dY, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, s));
     GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dY, wt + o.projw, M, C, C, C, C, &d3, s));
     const float* biasP = e->cfg.use_shared_rel_pos_bias ? e->biasP_s : nullptr;
@@ -508,7 +508,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     e->slab_started = true;
     CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 0, C, M, g + o.qb, s));
     CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 2 * C, C, M, g + o.vb, s));
-    CHECK(uvit_gemm_tn_launch(e->dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, s));
+    CHECK(uvit_gemm_tn_launch(e->dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, s));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
     CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, g + o.n1w, g + o.n1b, M, C, s));
@@ -524,7 +524,7 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
     CHECK(uvit_token_bwd_launch(e->dXa, e->mask_copy, e->dpatch, g + lo.cls, g + lo.mask_tok, e->B, e->P, C, s));
     CHECK(uvit_colsum_launch(e->dpatch, C, 0, C, BP, g + lo.peb, s));
-    CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, s));
+    CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, 1, s));
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     return UVIT_OK;
@@ -575,7 +575,8 @@ extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, in
 }
 extern "C" int uvit_op_gemm_tn(const void* Y, const void* X, int M, int N, int K, int ldy, int ldx, float* C, int ldc, uvit_stream st) {
     if (!Y || !X || !C) return UVIT_ERR_ARG;
-    return uvit_gemm_tn_launch(Y, X, M, N, K, ldy, ldx, C, ldc, S(st));
+    if (hipMemsetAsync(C, 0, (size_t)N * ldc * sizeof(float), S(st)) != hipSuccess) return UVIT_ERR_LAUNCH;
+    return uvit_gemm_tn_launch(Y, X, M, N, K, ldy, ldx, C, ldc, 1, S(st));
 }
 extern "C" int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
                                 float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {

@@ -195,10 +195,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col0, int kk, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
+#define TN_OUT_LD 132                                   // padded fp32 row of the staged output tile
+#define TN_LDS_BYTES (BM * TN_OUT_LD * 4)               // 67584 B >= 4 * STAGE_BYTES
+
+// grid = (output tiles, split): split s reduces token rows [s*steps_per_split*64, ...) and the
+// partial tiles are combined with fp32 atomics (the gradient arena is zeroed once per step).
+// The accumulators are re-laid out through LDS so every atomic wave-instruction covers 256
+// contiguous bytes of one output row (the full-rate shape for global float atomics).
 __global__ __launch_bounds__(GEMM_THREADS, 2)
 void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int M, int Nn, int Kk,
-                    int ldy, int ldx, float* __restrict__ C, int ldc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Y tile 16K | X tile 16K]
+                    int ldy, int ldx, float* __restrict__ C, int ldc, int steps_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Y tile 16K | X tile 16K], reused for the output
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_k = (Kk + BN - 1) / BN, tiles_n = (Nn + BM - 1) / BM;
     const int bid = xcd_remap(blockIdx.x, tiles_n * tiles_k);
@@ -206,6 +213,10 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
     const int n0 = tn * BM, k0 = tk * BN;
     const int wr = wave >> 1, wc = wave & 1;
     const int g = lane >> 4, li = lane & 15;
+    const int nm_total = M / BK;
+    const int m_begin = blockIdx.y * steps_per_split;
+    const int nm = min(steps_per_split, nm_total - m_begin);
+    if (nm <= 0) return;
 
     // staging: wave-instruction ii (0..15) fills tile rows ii*4..ii*4+3 (256-B rows)
     const int srow = lane >> 4, pchunk = lane & 15;
@@ -217,8 +228,8 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
         const int sch = pchunk ^ tn_swz(row);
         int yc = n0 / 8 + sch; yc = yc < Nn / 8 ? yc : Nn / 8 - 1;
         int xc = k0 / 8 + sch; xc = xc < Kk / 8 ? xc : Kk / 8 - 1;
-        y_src[i] = Y + (size_t)row * ldy + yc * 8;
-        x_src[i] = X + (size_t)row * ldx + xc * 8;
+        y_src[i] = Y + ((size_t)m_begin * BK + row) * ldy + yc * 8;
+        x_src[i] = X + ((size_t)m_begin * BK + row) * ldx + xc * 8;
     }
     auto stage = [&](int buf, int mt) {
         char* base = smem + buf * (2 * STAGE_BYTES);
@@ -237,7 +248,6 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nm = M / BK;
     stage(0, 0);
     for (int mt = 0; mt < nm; ++mt) {
         const int cur = mt & 1;
@@ -262,17 +272,41 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
                     acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[kt], yf[nt], acc[nt][kt], 0, 0, 0);
         }
     }
+    if (gridDim.y == 1) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wr * 64 + nt * 16 + li;
-        if (n >= Nn) continue;
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wr * 64 + nt * 16 + li;
+            if (n >= Nn) continue;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int k = k0 + wc * 64 + kt * 16 + 4 * g;
+                if (k < Kk) {
+                    const f32x4 a = acc[nt][kt];
+                    *(float4*)(C + (size_t)n * ldc + k) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            }
+        }
+        return;
+    }
+    // split: stage the 128x128 fp32 tile in LDS, then row-contiguous atomics
+    __syncthreads();
+    float* ot = (float*)smem;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const int k = k0 + wc * 64 + kt * 16 + 4 * g;
-            if (k < Kk) {
-                const f32x4 a = acc[nt][kt];
-                *(float4*)(C + (size_t)n * ldc + k) = make_float4(a[0], a[1], a[2], a[3]);
-            }
+            const f32x4 a = acc[nt][kt];
+            *(float4*)(ot + (wr * 64 + nt * 16 + li) * TN_OUT_LD + wc * 64 + kt * 16 + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    __syncthreads();
+    for (int r = wave; r < BM; r += 4) {
+        const int n = n0 + r;
+        if (n >= Nn) break;
+        float* dst = C + (size_t)n * ldc + k0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = h * 64 + lane;
+            if (k0 + k < Kk) atomicAdd(dst + k, ot[r * TN_OUT_LD + k]);
         }
     }
 }
@@ -288,7 +322,8 @@ static void gemm_init_once() {
     if (g_attr_done) return;
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
-    allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_tn_kernel);
+    allow_lds(gemm_nt_kernel<EPI_DGELU>);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     g_attr_done = true;
 }
 
@@ -316,11 +351,21 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
 }
 
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
-                        int ldc, hipStream_t s) {
+                        int ldc, int allow_split, hipStream_t s) {
     if (M <= 0 || (M % BK) || (Nn % 8) || (Kk % 8) || (ldy % 8) || (ldx % 8) || (ldc % 4)) return UVIT_ERR_SHAPE;
     gemm_init_once();
-    const int grid = ((Nn + BM - 1) / BM) * ((Kk + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(GEMM_THREADS), 4 * STAGE_BYTES, s, (const bf16*)Y,
-                       (const bf16*)X, M, Nn, Kk, ldy, ldx, C, ldc);
+    const int tiles = ((Nn + BM - 1) / BM) * ((Kk + BN - 1) / BN);
+    const int nm = M / BK;
+    // split the token reduction until ~1024 workgroups are in flight (2 resident per CU x 256 CUs, two rounds)
+    int split = 1;
+    if (allow_split) {
+        split = 1024 / tiles;
+        if (split > nm / 8) split = nm / 8;
+        if (split < 1) split = 1;
+    }
+    const int steps = (nm + split - 1) / split;
+    split = (nm + steps - 1) / steps;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, split), dim3(GEMM_THREADS), TN_LDS_BYTES, s, (const bf16*)Y,
+                       (const bf16*)X, M, Nn, Kk, ldy, ldx, C, ldc, steps);
     return uvit_check_launch();
 }

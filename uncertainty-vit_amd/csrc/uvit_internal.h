@@ -24,8 +24,9 @@ struct GemmEpi {
 // gemm.hip
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
                         const GemmEpi* epi, hipStream_t s);
+// allow_split: partial sums are combined with fp32 atomics -> C must be zero (or hold a value to add to)
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
-                        int ldc, hipStream_t s);
+                        int ldc, int allow_split, hipStream_t s);
 
 // attention.hip
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
