@@ -68,6 +68,32 @@ def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
     close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (2048, 768, 3072), (1100, 2304, 768), (1024, 256, 128)])
+def test_gemm_nt_large_tile_kernel(L, M, N, K):
+    """Shapes that dispatch to the 256x256 deep-prefetch kernel (N % 256 == 0, M >= 1024): parity, a ragged
+    last row tile, and a race screen (the counted-vmcnt pipeline must give bit-identical results every launch)."""
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out32 = torch.zeros(M, N, device="cuda")
+    ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+    close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
+    first = out32.clone()
+    for _ in range(10):
+        out32.zero_()
+        ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+        assert torch.equal(out32, first), "non-deterministic result: LDS pipeline race"
+
+
+def test_gemm_nt_large_identity(L):
+    """A = [I; I; ...] against an asymmetric W on the 256x256 kernel: exact, catches any fragment / quadrant mix-up."""
+    K, N, M = 256, 512, 2048
+    a = bf(torch.eye(K).repeat(M // K, 1).cuda())
+    w = bf(((torch.arange(N * K).reshape(N, K) * 7) % 509 - 254).float().cuda() / 128)
+    out = torch.zeros(M, N, device="cuda")
+    ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, ldo=N)), S()))
+    torch.testing.assert_close(out, w.float().t().repeat(M // K, 1).contiguous(), rtol=0, atol=0)
+
+
 def test_gemm_nt_asymmetric_identity(L):
     """A = I with an asymmetric W catches a transposed C write (guide section 3)."""
     K = 128

@@ -1,0 +1,81 @@
+"""Micro-benchmark of the GEMM kernels through the C ABI (run on the GPU box)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from uncertainty_vit_amd import native  # noqa: E402
+from uncertainty_vit_amd.native import GemmEpilogue  # noqa: E402
+
+L = native.lib()
+S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+
+def time_nt(mode, M, N, K, iters=20):
+    a = (torch.randn(M, K, device="cuda")).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda")
+    gamma = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda") if mode == 3 else None
+    aux = torch.randn(M, N, device="cuda").to(torch.bfloat16) if mode == 6 else None
+    out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if mode in (3, 4) else torch.bfloat16)
+    out2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if mode in (2, 3) else None
+    e = GemmEpilogue()
+    e.out = out.data_ptr(); e.out2 = out2.data_ptr() if out2 is not None else 0
+    e.bias = bias.data_ptr(); e.bias2 = bias.data_ptr(); e.gamma = gamma.data_ptr()
+    e.resid = resid.data_ptr() if resid is not None else 0
+    e.aux = aux.data_ptr() if aux is not None else 0
+    e.ldo, e.tokens, e.patches = N, 197, 196
+    for _ in range(3):
+        assert L.uvit_op_gemm_nt(mode, P(a), P(w), M, N, K, K, K, C.byref(e), S()) == 0
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        L.uvit_op_gemm_nt(mode, P(a), P(w), M, N, K, K, K, C.byref(e), S())
+    en.record()
+    torch.cuda.synchronize()
+    us = st.elapsed_time(en) / iters * 1e3
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+def time_tn(M, N, K, iters=20):
+    y = (torch.randn(M, N, device="cuda") * 0.1).to(torch.bfloat16)
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    out = torch.zeros(N, K, device="cuda")
+    for _ in range(3):
+        assert L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()) == 0
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S())
+    en.record()
+    torch.cuda.synchronize()
+    us = st.elapsed_time(en) / iters * 1e3
+    return us, 2.0 * M * N * K / us / 1e6
+
+
+if __name__ == "__main__":
+    M = 25216
+    names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu"}
+    print("== NT: K sweep (mode bf16) ==")
+    for N in (3072, 768):
+        for K in (128, 256, 768, 1536, 3072, 6144):
+            us, tf = time_nt(0, M, N, K)
+            print(f"N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
+    print("== NT: step shapes ==")
+    for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
+        us, tf = time_nt(mode, M, N, K)
+        print(f"{names[mode]:6s} N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
+    print("== NT: square references ==")
+    for n in (4096, 8192):
+        us, tf = time_nt(0, n, n, n, iters=5)
+        print(f"{n}^3: {us:8.1f} us  {tf:7.1f} TF/s")
+    print("== TN (wgrad) ==")
+    for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+        us, tf = time_tn(M, N, K)
+        print(f"wgrad N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")

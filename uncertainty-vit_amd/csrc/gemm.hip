@@ -25,65 +25,89 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 }
 
 // ------------------------------------------------------------------------------------------
-// epilogue: acc[j] holds C[m][n..n+3]
+// epilogue: acc[j] holds C[m][n..n+3].  Per-column operands (bias, gamma) are loaded once per
+// column group into a ColVals before the row loops (no dependent load chain in the store tail).
 // ------------------------------------------------------------------------------------------
+struct ColVals { float4 b; float4 g; };
+
 template <int MODE>
-__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n, int N, f32x4 acc) {
+__device__ __forceinline__ ColVals load_cols(const GemmEpi& e, int n, int N) {
+    ColVals c;
+    c.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    c.g = c.b;
+    if constexpr (MODE == EPI_QKV) {
+        // bias = cat(q_bias, 0, v_bias)  (modeling_finetune.py:149-151)
+        const int C = N / 3;
+        if (n < C) c.b = *(const float4*)(e.bias + n);
+        else if (n >= 2 * C) c.b = *(const float4*)(e.bias2 + (n - 2 * C));
+    } else if constexpr (MODE == EPI_BF16 || MODE == EPI_F32) {
+        if (e.bias) c.b = *(const float4*)(e.bias + n);
+    } else if constexpr (MODE == EPI_GELU || MODE == EPI_PATCH) {
+        c.b = *(const float4*)(e.bias + n);
+        if constexpr (MODE == EPI_PATCH) c.g = *(const float4*)(e.mask_token + n);
+    } else if constexpr (MODE == EPI_RESID) {
+        c.b = *(const float4*)(e.bias + n);
+        c.g = *(const float4*)(e.gamma + n);
+    }
+    return c;
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7): one v_rcp + one v_exp + 6 FMAs instead of libm erff
+__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    gauss = __expf(-z * z);                                   // exp(-x^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * gauss;
+    erf_v = x < 0.f ? -e : e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float e, gs; erf_parts(x, e, gs);
+    return 0.5f * x * (1.0f + e);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float e, gs; erf_parts(x, e, gs);
+    return 0.5f * (1.0f + e) + x * 0.39894228040143268f * gs;
+}
+
+template <int MODE>
+__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n, const ColVals& cv, f32x4 acc) {
     const size_t o = (size_t)m * e.ldo + n;
-    if constexpr (MODE == EPI_BF16 || MODE == EPI_F32 || MODE == EPI_QKV) {
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == EPI_QKV) {
-            // bias = cat(q_bias, 0, v_bias)  (modeling_finetune.py:149-151)
-            const int C = N / 3;
-            const float* src = n < C ? e.bias + n : (n >= 2 * C ? e.bias2 + (n - 2 * C) : nullptr);
-            if (src) { const float4 t = *(const float4*)src; b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w; }
-        } else if (e.bias) {
-            const float4 t = *(const float4*)(e.bias + n); b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
-        }
-        if constexpr (MODE == EPI_F32) {
-            *(float4*)((float*)e.out + o) = make_float4(acc[0] + b[0], acc[1] + b[1], acc[2] + b[2], acc[3] + b[3]);
-        } else {
-            bf16x4 v = {f2bf(acc[0] + b[0]), f2bf(acc[1] + b[1]), f2bf(acc[2] + b[2]), f2bf(acc[3] + b[3])};
-            *(bf16x4*)((bf16*)e.out + o) = v;
-        }
+    if constexpr (MODE == EPI_BF16 || MODE == EPI_QKV) {
+        bf16x4 v = {f2bf(acc[0] + cv.b.x), f2bf(acc[1] + cv.b.y), f2bf(acc[2] + cv.b.z), f2bf(acc[3] + cv.b.w)};
+        *(bf16x4*)((bf16*)e.out + o) = v;
+    } else if constexpr (MODE == EPI_F32) {
+        *(float4*)((float*)e.out + o) = make_float4(acc[0] + cv.b.x, acc[1] + cv.b.y, acc[2] + cv.b.z, acc[3] + cv.b.w);
     } else if constexpr (MODE == EPI_GELU) {
-        const float4 t = *(const float4*)(e.bias + n);
-        const float h0 = acc[0] + t.x, h1 = acc[1] + t.y, h2 = acc[2] + t.z, h3 = acc[3] + t.w;
         // pre-activation is kept in bf16 for backward; GELU is evaluated on the rounded value so
         // forward and backward see the same h
-        bf16x4 hv = {f2bf(h0), f2bf(h1), f2bf(h2), f2bf(h3)};
+        bf16x4 hv = {f2bf(acc[0] + cv.b.x), f2bf(acc[1] + cv.b.y), f2bf(acc[2] + cv.b.z), f2bf(acc[3] + cv.b.w)};
         if (e.out2) *(bf16x4*)((bf16*)e.out2 + o) = hv;
-        bf16x4 av = {f2bf(gelu_exact(bf2f(hv[0]))), f2bf(gelu_exact(bf2f(hv[1]))),
-                     f2bf(gelu_exact(bf2f(hv[2]))), f2bf(gelu_exact(bf2f(hv[3])))};
+        bf16x4 av = {f2bf(gelu_fast(bf2f(hv[0]))), f2bf(gelu_fast(bf2f(hv[1]))), f2bf(gelu_fast(bf2f(hv[2]))), f2bf(gelu_fast(bf2f(hv[3])))};
         *(bf16x4*)((bf16*)e.out + o) = av;
     } else if constexpr (MODE == EPI_RESID) {
         // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
-        const float4 t = *(const float4*)(e.bias + n);
-        const float4 g = *(const float4*)(e.gamma + n);
         const float4 r = *(const float4*)(e.resid + o);
         const float dp = e.rowscale ? e.rowscale[m / e.tokens] : 1.0f;
-        const float y0 = acc[0] + t.x, y1 = acc[1] + t.y, y2 = acc[2] + t.z, y3 = acc[3] + t.w;
+        const float y0 = acc[0] + cv.b.x, y1 = acc[1] + cv.b.y, y2 = acc[2] + cv.b.z, y3 = acc[3] + cv.b.w;
         if (e.out2) {
             bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
             *(bf16x4*)((bf16*)e.out2 + o) = yv;
         }
-        *(float4*)((float*)e.out + o) = make_float4(r.x + dp * g.x * y0, r.y + dp * g.y * y1,
-                                                    r.z + dp * g.z * y2, r.w + dp * g.w * y3);
+        *(float4*)((float*)e.out + o) = make_float4(r.x + dp * cv.g.x * y0, r.y + dp * cv.g.y * y1,
+                                                    r.z + dp * cv.g.z * y2, r.w + dp * cv.g.w * y3);
     } else if constexpr (MODE == EPI_PATCH) {
         // row m = b*P + p of the patch GEMM lands in token row b*(P+1) + 1 + p; masked patches take
         // the mask token (modeling_cyclical.py:179-182)
         const int b = m / e.patches, p = m - b * e.patches;
         const size_t orow = (size_t)(b * (e.patches + 1) + 1 + p) * e.ldo + n;
         const bool masked = e.mask && e.mask[m] != 0;
-        const float4 t = masked ? *(const float4*)(e.mask_token + n) : *(const float4*)(e.bias + n);
-        float4 v;
-        if (masked) v = t;
-        else v = make_float4(acc[0] + t.x, acc[1] + t.y, acc[2] + t.z, acc[3] + t.w);
+        const float4 v = masked ? cv.g : make_float4(acc[0] + cv.b.x, acc[1] + cv.b.y, acc[2] + cv.b.z, acc[3] + cv.b.w);
         *(float4*)((float*)e.out + orow) = v;
     } else if constexpr (MODE == EPI_DGELU) {
         const bf16x4 h = *(const bf16x4*)((const bf16*)e.aux + o);
-        bf16x4 v = {f2bf(acc[0] * gelu_grad(bf2f(h[0]))), f2bf(acc[1] * gelu_grad(bf2f(h[1]))),
-                    f2bf(acc[2] * gelu_grad(bf2f(h[2]))), f2bf(acc[3] * gelu_grad(bf2f(h[3])))};
+        bf16x4 v = {f2bf(acc[0] * gelu_grad_fast(bf2f(h[0]))), f2bf(acc[1] * gelu_grad_fast(bf2f(h[1]))),
+                    f2bf(acc[2] * gelu_grad_fast(bf2f(h[2]))), f2bf(acc[3] * gelu_grad_fast(bf2f(h[3])))};
         *(bf16x4*)((bf16*)e.out + o) = v;
     }
 }
@@ -163,6 +187,12 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
         }
     }
     // D layout (swapped operands): lane col (li) = m_local, rows 4g+r = n_local
+    ColVals cv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+        cv[nt] = load_cols<MODE>(epi, n < N ? n : 0, N);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wr * 64 + mt * 16 + li;
@@ -170,9 +200,165 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wc * 64 + nt * 16 + 4 * g;
-            if (n < N) epilogue4<MODE>(epi, m, n, N, acc[mt][nt]);
+            if (n < N) epilogue4<MODE>(epi, m, n, cv[nt], acc[mt][nt]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, large shapes: 256x256 block tile, BK = 64, 8 waves (2 M x 4 N), one block per CU.
+//
+// LDS = 2 K-tile buffers x 4 half-tiles {AL, AH, BL, BH} of [128 rows][64 k] bf16 (16 KiB each,
+// 128 KiB total).  A wave owns output rows {wm*64.. in AL} u {wm*64.. in AH} and columns
+// {wn*32.. in BL} u {wn*32.. in BH}, so each K-tile is consumed in 4 phases of 16 MFMAs
+// (one 64x32 quadrant each) that read
+//        p0: AL + BL      p1: BH      p2: AH      p3: -  (BL fragments stay in registers)
+// A half-tile slot is therefore free one phase after its single read, and the loader refills it
+// immediately with the half-tile of K-tile t+2 (t+1 for AH): every global_load_lds has >= 6
+// phases (~3000 cycles) of flight time and 5 half-tiles (80 KiB) are in flight per CU while the
+// MFMA pipe works -- prefetch depth comes from the consumption order, not from more LDS.
+// Ordering: RAW by a counted `s_waitcnt vmcnt(10)` (5 younger half-tiles x 2 loads per thread)
+// placed one phase before the read and followed by that phase's barrier; WAR by the
+// lgkmcnt(0) + barrier that closes the reading phase.  Never vmcnt(0) in the steady state.
+// ------------------------------------------------------------------------------------------
+#define T_BM 256
+#define T_BN 256
+#define T_THREADS 512
+#define HALF_BYTES (128 * BK * 2)          // 16 KiB
+#define T_LDS_BYTES (8 * HALF_BYTES)       // 128 KiB
+
+#define VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define LDS_WAIT() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(T_THREADS, 2)
+void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
+                       int lda, int ldw, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = N / T_BN, tiles_m = (M + T_BM - 1) / T_BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * T_BM, n0 = tn * T_BN;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+
+    // ---- loader: half-tile = 16 wave-instructions of 8 rows; this wave issues instructions {wave, 8 + wave}
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;              // swizzle on the SOURCE side (LDS image stays lane-linear)
+    const bf16* src[4][2];                             // [AL, AH, BL, BH][instruction]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 8 + wave) * 8 + srow;       // row inside the half-tile
+        int ra = m0 + r;        ra = ra < M ? ra : M - 1;
+        int rb = m0 + 128 + r;  rb = rb < M ? rb : M - 1;
+        src[0][j] = A + (size_t)ra * lda + schunk * 8;
+        src[1][j] = A + (size_t)rb * lda + schunk * 8;
+        src[2][j] = W + (size_t)(n0 + r) * ldw + schunk * 8;
+        src[3][j] = W + (size_t)(n0 + 128 + r) * ldw + schunk * 8;
+    }
+    const int nk = K / BK;
+    auto issue = [&](int kind, int t) {                // half-tile `kind` of K-tile t -> buffer t&1
+        if (t < nk) {
+            char* dst = smem + (t & 1) * (4 * HALF_BYTES) + kind * HALF_BYTES + wave * 1024;
+            glds16(src[kind][0] + (size_t)t * BK, dst);
+            glds16(src[kind][1] + (size_t)t * BK, dst + 8 * 1024);
+        }
+    };
+
+    // ---- fragment addressing: row*128 + ((chunk ^ (row&7)) << 4); (row & 7) == (li & 7) for every tile row
+    const int sw0 = ((g) ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
+    const int a_off = (wm * 64 + li) * 128, b_off = (wn * 32 + li) * 128;
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
+#define LOAD_A(half_base) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { \
+        af[mt][0] = *(const bf16x8*)((half_base) + a_off + mt * 2048 + sw0); \
+        af[mt][1] = *(const bf16x8*)((half_base) + a_off + mt * 2048 + sw1); }
+#define LOAD_B(dst, half_base) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) { \
+        dst[nt][0] = *(const bf16x8*)((half_base) + b_off + nt * 2048 + sw0); \
+        dst[nt][1] = *(const bf16x8*)((half_base) + b_off + nt * 2048 + sw1); }
+#define MMA(mq, nq, bfr) do { __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
+            acc[mq][nq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][kk], af[mt][kk], acc[mq][nq][mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0); } while (0)
+
+    // ---- prologue: AL0 BL0 BH0 AH0 AL1 BL1 BH1 (AH1 is issued in phase 0 of tile 0)
+    issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
+    issue(0, 1); issue(2, 1); issue(3, 1);
+    if (nk >= 2) VM_WAIT(10); else VM_WAIT(0);         // AL0, BL0 landed (5 younger half-tiles may fly)
+    RAW_BARRIER();
+
+    for (int t = 0; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * (4 * HALF_BYTES);
+        const bool steady2 = t + 2 < nk;               // the load this phase would issue exists
+        // ---- phase 0: quadrant (0,0) <- AL, BL
+        LOAD_A(buf);
+        LOAD_B(b0f, buf + 2 * HALF_BYTES);
+        issue(1, t + 1);                               // AH(t+1): its slot was last read in phase 2 of tile t-1
+        if (t + 1 < nk) VM_WAIT(10); else VM_WAIT(0);  // BH(t) landed -> read next phase
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(0, 0, b0f);
+        RAW_BARRIER();
+        // ---- phase 1: quadrant (0,1) <- BH
+        LOAD_B(b1f, buf + 3 * HALF_BYTES);
+        issue(0, t + 2);                               // AL(t+2): slot read in phase 0
+        if (steady2) VM_WAIT(10); else VM_WAIT(0);     // AH(t) landed
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(0, 1, b1f);
+        RAW_BARRIER();
+        // ---- phase 2: quadrant (1,1) <- AH
+        LOAD_A(buf + HALF_BYTES);
+        issue(2, t + 2);                               // BL(t+2): slot read in phase 0 (fragments live in registers)
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(1, 1, b1f);
+        RAW_BARRIER();
+        // ---- phase 3: quadrant (1,0), no LDS read
+        issue(3, t + 2);                               // BH(t+2): slot read in phase 1
+        if (steady2) VM_WAIT(10); else VM_WAIT(0);     // AL(t+1), BL(t+1) landed
+        RAW_BARRIER();
+        MMA(1, 0, b0f);
+        RAW_BARRIER();
+    }
+#undef LOAD_A
+#undef LOAD_B
+#undef MMA
+
+    // D layout (swapped operands): lane col (li) = m_local, rows 4g+r = n_local
+    ColVals cv[2][2];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) cv[nq][nt] = load_cols<MODE>(epi, n0 + nq * 128 + wn * 32 + nt * 16 + 4 * g, N);
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + mq * 128 + wm * 64 + mt * 16 + li;
+            if (m >= M) continue;
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    epilogue4<MODE>(epi, m, n0 + nq * 128 + wn * 32 + nt * 16 + 4 * g, cv[nq][nt], acc[mq][nq][mt][nt]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -315,6 +501,8 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
 // host launchers
 // ------------------------------------------------------------------------------------------
 static bool g_attr_done = false;
+static bool g_use_256 = true;
+void uvit_gemm_set_variant(int use_256) { g_use_256 = use_256 != 0; }
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
@@ -323,6 +511,9 @@ static void gemm_init_once() {
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>);
+#define ALLOW256(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES)
+    ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU);
+#undef ALLOW256
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     g_attr_done = true;
 }
@@ -332,10 +523,12 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
-    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const bool big = g_use_256 && (N % T_BN) == 0 && M >= 1024 && K >= 2 * BK;
+    const int grid = big ? ((M + T_BM - 1) / T_BM) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
-#define L(MODE) hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi)
+#define L(MODE) do { if (big) hipLaunchKernelGGL(gemm_nt256_kernel<MODE>, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+        else hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi); } while (0)
     switch (mode) {
         case EPI_BF16: L(EPI_BF16); break;
         case EPI_QKV: if (N % 3) return UVIT_ERR_SHAPE; L(EPI_QKV); break;
