@@ -92,10 +92,11 @@ __global__ void relpos_scatter_kernel(const float* __restrict__ slab, int nslab,
 #define CP_MAXV 8
 #define CP_ROWS 32
 
-__device__ __forceinline__ void block_col_atomic(float4 (&acc)[CP_MAXV], float* out, int nv, float (*red)[64 * 4]) {
+template <int NV>
+__device__ __forceinline__ void block_col_atomic(float4 (&acc)[NV], float* out, int nv, float (*red)[64 * 4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < CP_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         if (64 * k < nv) {
             __syncthreads();
             ((float4*)red[wave])[lane] = acc[k];
@@ -114,20 +115,22 @@ __device__ __forceinline__ void block_col_atomic(float4 (&acc)[CP_MAXV], float* 
 // LayerScale + DropPath backward (modeling_finetune.py:295-298):
 //   dy = dx * gamma * dp[b]   (bf16, gradient of the Linear output y)
 //   dgamma += sum_m dx * dp * y ;  dbias += sum_m dy
+template <int NV>
 __global__ __launch_bounds__(256)
 void ls_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, const float* __restrict__ gamma,
                    const float* __restrict__ rowscale, bf16* __restrict__ dy, float* __restrict__ dgamma,
-                   float* __restrict__ dbias, int M, int C, int tokens) {
+                   float* __restrict__ dbias, int M, int C, int tokens, int nrep, size_t rep_stride) {
     __shared__ float red[4][64 * 4];
+    dgamma += (size_t)(blockIdx.x % nrep) * rep_stride; dbias += (size_t)(blockIdx.x % nrep) * rep_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2;
-    float4 ag[CP_MAXV], ab[CP_MAXV];
+    float4 ag[NV], ab[NV];
 #pragma unroll
-    for (int k = 0; k < CP_MAXV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
+    for (int k = 0; k < NV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
     const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
     for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
         const float dp = rowscale ? rowscale[row / tokens] : 1.0f;
 #pragma unroll
-        for (int k = 0; k < CP_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
                 const float4 d = ((const float4*)(dx + (size_t)row * C))[i];
@@ -145,26 +148,39 @@ void ls_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, con
     block_col_atomic(ab, dbias, nv, red);
 }
 
-// out[c] += sum_m y[m][col0 + c]
+// out[c] += sum_m y[m][col0 + c]: lane = 8 columns (16 B), wave = 512 columns, 4 waves walk rows 4-way unrolled
+#define CS_ROWS 256
 __global__ __launch_bounds__(256)
-void colsum_kernel(const bf16* __restrict__ y, int ld, int col0, int ncols, int M, float* __restrict__ out) {
-    __shared__ float red[4][64 * 4];
+void colsum_kernel(const bf16* __restrict__ y, int ld, int col0, int ncols, int M, float* __restrict__ out, int nrep, size_t rep_stride) {
+    __shared__ float red[4][64 * 8];
+    out += (size_t)(blockIdx.y % nrep) * rep_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 256 + lane * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int row_end = min((int)(blockIdx.y + 1) * 128, M);
-    if (c < ncols)
-        for (int row = blockIdx.y * 128 + wave; row < row_end; row += 4) {
-            const bf16x4 v = *(const bf16x4*)(y + (size_t)row * ld + col0 + c);
-            acc.x += bf2f(v[0]); acc.y += bf2f(v[1]); acc.z += bf2f(v[2]); acc.w += bf2f(v[3]);
-        }
-    ((float4*)red[wave])[lane] = acc;
-    __syncthreads();
-    if (wave == 0 && c < ncols) {
-        float4 s = ((float4*)red[0])[lane];
+    const int c = blockIdx.x * 512 + lane * 8;
+    float acc[8];
 #pragma unroll
-        for (int q = 1; q < 4; ++q) { const float4 a = ((float4*)red[q])[lane]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
-        atomicAdd(out + c, s.x); atomicAdd(out + c + 1, s.y); atomicAdd(out + c + 2, s.z); atomicAdd(out + c + 3, s.w);
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int row_end = min((int)(blockIdx.y + 1) * CS_ROWS, M);
+    if (c < ncols) {
+        const bf16* base = y + col0 + c;
+        int row = blockIdx.y * CS_ROWS + wave;
+        for (; row + 12 < row_end; row += 16) {
+            const bf16x8 v0 = *(const bf16x8*)(base + (size_t)row * ld), v1 = *(const bf16x8*)(base + (size_t)(row + 4) * ld);
+            const bf16x8 v2 = *(const bf16x8*)(base + (size_t)(row + 8) * ld), v3 = *(const bf16x8*)(base + (size_t)(row + 12) * ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (bf2f(v0[j]) + bf2f(v1[j])) + (bf2f(v2[j]) + bf2f(v3[j]));
+        }
+        for (; row < row_end; row += 4) {
+            const bf16x8 v = *(const bf16x8*)(base + (size_t)row * ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int cc = blockIdx.x * 512 + i;
+        if (cc < ncols) atomicAdd(out + cc, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
     }
 }
 
@@ -209,14 +225,15 @@ void smooth_l1_kernel(const float* __restrict__ out, const float* __restrict__ t
 // token-assembly backward (modeling_cyclical.py:179-192):  dpatch = (1-w) * dx[:,1:],
 // dcls += sum_b dx[b,0], dmask_token += sum_masked dx
 // ------------------------------------------------------------------------------------------
+template <int NV>
 __global__ __launch_bounds__(256)
 void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ mask, bf16* __restrict__ dpatch,
                       float* __restrict__ dcls, float* __restrict__ dmask, int B, int P, int C) {
     __shared__ float red[4][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2, N = P + 1;
-    float4 ac[CP_MAXV], am[CP_MAXV];
+    float4 ac[NV], am[NV];
 #pragma unroll
-    for (int k = 0; k < CP_MAXV; ++k) { ac[k] = make_float4(0.f, 0.f, 0.f, 0.f); am[k] = ac[k]; }
+    for (int k = 0; k < NV; ++k) { ac[k] = make_float4(0.f, 0.f, 0.f, 0.f); am[k] = ac[k]; }
     const int M = B * N;
     const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
     for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
@@ -224,7 +241,7 @@ void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ 
         const bool is_cls = t == 0;
         const bool masked = !is_cls && mask[b * P + t - 1] != 0;
 #pragma unroll
-        for (int k = 0; k < CP_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
                 const float4 d = ((const float4*)(dx + (size_t)row * C))[i];
@@ -285,6 +302,11 @@ __global__ void droppath_kernel(float* __restrict__ scales, const float* __restr
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+#define CP_DISPATCH(KERNEL, C, ...) do { const int _nv = ((C) + 255) / 256; \
+    if (_nv <= 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (_nv == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); \
+    else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
+    else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
+
 static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
     size_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
@@ -317,15 +339,15 @@ int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, f
     return uvit_check_launch();
 }
 int uvit_ls_bwd_launch(const float* dx, const void* y, const float* gamma, const float* rowscale, void* dy,
-                       float* dgamma, float* dbias, int M, int C, int tokens, hipStream_t s) {
+                       float* dgamma, float* dbias, int M, int C, int tokens, int nrep, size_t rep_stride, hipStream_t s) {
     if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ls_bwd_kernel, dim3((M + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, (const bf16*)y, gamma, rowscale,
-                       (bf16*)dy, dgamma, dbias, M, C, tokens);
+    CP_DISPATCH(ls_bwd_kernel, C, dim3((M + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, (const bf16*)y, gamma, rowscale,
+                       (bf16*)dy, dgamma, dbias, M, C, tokens, nrep > 0 ? nrep : 1, rep_stride);
     return uvit_check_launch();
 }
-int uvit_colsum_launch(const void* y, int ld, int col0, int ncols, int M, float* out, hipStream_t s) {
-    if (ncols % 4 || col0 % 4 || ld % 4) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(colsum_kernel, dim3((ncols + 255) / 256, (M + 127) / 128), dim3(256), 0, s, (const bf16*)y, ld, col0, ncols, M, out);
+int uvit_colsum_launch(const void* y, int ld, int col0, int ncols, int M, float* out, int nrep, size_t rep_stride, hipStream_t s) {
+    if (ncols % 8 || col0 % 8 || ld % 8) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(colsum_kernel, dim3((ncols + 511) / 512, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, (const bf16*)y, ld, col0, ncols, M, out, nrep > 0 ? nrep : 1, rep_stride);
     return uvit_check_launch();
 }
 int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,
@@ -338,7 +360,7 @@ int uvit_smooth_l1_launch(const float* out, const float* target, const int* coun
 int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch, float* dcls, float* dmask_token, int B,
                           int P, int C, hipStream_t s) {
     if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(token_bwd_kernel, dim3((B * (P + 1) + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
+    CP_DISPATCH(token_bwd_kernel, C, dim3((B * (P + 1) + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
                        dcls, dmask_token, B, P, C);
     return uvit_check_launch();
 }

@@ -13,6 +13,8 @@
 #include "uvit_internal.h"
 
 #define CHECK(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define NREP 32
+#define RP(off) (e->grep + ((off) - e->lo.n_decay))   // replica 0 address of a no-decay gradient
 #define HIPCHECK(x) do { if ((x) != hipSuccess) return UVIT_ERR_LAUNCH; } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -121,6 +123,8 @@ struct uvit_engine {
     float *loss, *gnorm; double* sumsq;
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
+    float* grep;           // [NREP][no-decay region] replicated column-sum accumulators
+    size_t n_nd;           // floats in the no-decay region
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
     // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
@@ -172,6 +176,7 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->tdesc = b.take<TransposeDesc>(5 * c.depth + 2);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
+    e->grep = b.take<float>((size_t)NREP * e->n_nd);
 }
 
 static void fill_dims(uvit_engine* e) {
@@ -183,6 +188,8 @@ static void fill_dims(uvit_engine* e) {
     e->chunk = c.bias_chunk > 0 ? c.bias_chunk : 8;
     e->nchunk = (e->B + e->chunk - 1) / e->chunk;
     e->cur_B = e->B;
+    Layout tmp_lo; build_layout(&e->cfg, tmp_lo);
+    e->n_nd = tmp_lo.n_total - tmp_lo.n_decay;
 }
 
 extern "C" int uvit_version(void) { return UVIT_VERSION; }
@@ -445,6 +452,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // zero the accumulated (atomic) gradient ranges + step scalars
     // every gradient is accumulated (split-K wgrad atomics, bias/LN/gamma column sums): zero the arena once
     HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), s));
+    HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), s));
     HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), s));
     e->slab_started = false;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
@@ -461,14 +469,14 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // lm_head backward
     float* g = e->buf.grads;
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
-    CHECK(uvit_colsum_launch(e->dout, C, 0, C, BP, g + lo.lmb, s));
+    CHECK(uvit_colsum_launch(e->dout, C, 0, C, BP, RP(lo.lmb), NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dout, e->normed, e->BPpad, C, C, C, C, g + lo.lmw, C, 1, s));
     GemmEpi d; d.out = e->dnormed; d.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout, wt + lo.lmw, BP, C, C, C, C, &d, s));
     // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
     HIPCHECK(hipMemsetAsync(e->dXa, 0, (size_t)e->M * C * sizeof(float), s));
     CHECK(uvit_ln_bwd_scatter_launch(e->dnormed, e->X[e->cfg.depth], e->rowidx, e->count, e->meanF, e->rstdF,
-                                     e->buf.params + lo.normw, e->dXa, g + lo.normw, g + lo.normb, BP, C, s));
+                                     e->buf.params + lo.normw, e->dXa, RP(lo.normw), RP(lo.normb), BP, C, NREP, e->n_nd, s));
     return UVIT_OK;
 }
 
@@ -487,17 +495,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * e->B : nullptr;
     const float pdrop = e->last_dropout ? e->cfg.attn_drop_rate : 0.f;
     // --- MLP branch: x_out = x_mid + dp2 * gamma2 * (fc2(gelu(fc1(ln2(x_mid)))))
-    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, e->dY, g + o.g2, g + o.fc2b, M, C, e->N, s));
+    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, e->dY, RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dY, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, 1, s));
     GemmEpi d1; d1.out = e->dH; d1.aux = a.h; d1.ldo = Hd;
     CHECK(uvit_gemm_nt_launch(EPI_DGELU, e->dY, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
-    CHECK(uvit_colsum_launch(e->dH, Hd, 0, Hd, M, g + o.fc1b, s));
+    CHECK(uvit_colsum_launch(e->dH, Hd, 0, Hd, M, RP(o.fc1b), NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, 1, s));
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, g + o.n2w, g + o.n2b, M, C, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), M, C, NREP, e->n_nd, s));
     // --- attention branch: x_mid = x_in + dp1 * gamma1 * proj(attn(ln1(x_in)))
-    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, e->dY, g + o.g1, g + o.projb, M, C, e->N, s));
+    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, e->dY, RP(o.g1), RP(o.projb), M, C, e->N, NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dY, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, s));
     GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dY, wt + o.projw, M, C, C, C, C, &d3, s));
@@ -506,12 +514,12 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
                                e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed,
                                (uint32_t)l, s));
     e->slab_started = true;
-    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 0, C, M, g + o.qb, s));
-    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 2 * C, C, M, g + o.vb, s));
+    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 0, C, M, RP(o.qb), NREP, e->n_nd, s));
+    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 2 * C, C, M, RP(o.vb), NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, s));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, g + o.n1w, g + o.n1b, M, C, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), M, C, NREP, e->n_nd, s));
     return UVIT_OK;
 }
 
@@ -523,10 +531,12 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     const int C = e->C, BP = e->BP;
     // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
     CHECK(uvit_token_bwd_launch(e->dXa, e->mask_copy, e->dpatch, g + lo.cls, g + lo.mask_tok, e->B, e->P, C, s));
-    CHECK(uvit_colsum_launch(e->dpatch, C, 0, C, BP, g + lo.peb, s));
+    CHECK(uvit_colsum_launch(e->dpatch, C, 0, C, BP, RP(lo.peb), NREP, e->n_nd, s));
     CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, 1, s));
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
+    // fold the replicated column-sum accumulators into the no-decay gradients
+    CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
     return UVIT_OK;
 }
 
@@ -599,7 +609,7 @@ extern "C" int uvit_op_ln_fwd(const float* x, const float* w, const float* b, vo
                               float eps, uvit_stream st) { return uvit_ln_fwd_launch(x, w, b, y, mean, rstd, M, C, eps, S(st)); }
 extern "C" int uvit_op_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                               const float* dres, float* dx, float* dw, float* db, int M, int C, uvit_stream st) {
-    return uvit_ln_bwd_launch(dy, x, mean, rstd, w, dres, dx, dw, db, M, C, S(st));
+    return uvit_ln_bwd_launch(dy, x, mean, rstd, w, dres, dx, dw, db, M, C, 1, 0, S(st));
 }
 extern "C" int uvit_op_ema(float* ema, const float* p, void* eb, int64_t n, float d, uvit_stream st) {
     return uvit_ema_launch(ema, p, eb, (size_t)n, d, S(st));

@@ -10,26 +10,30 @@
 #define LN_MAXV 8          // float4 per lane: C <= 2048
 #define LN_WAVES 4
 
-struct RowVec { float4 v[LN_MAXV]; };
+// NV = float4 per lane actually needed (ceil(C / 256)): a template parameter so register use and
+// hence occupancy follow the real row length (NV = 3 for C = 768) instead of the maximum.
+template <int NV> struct RowVec { float4 v[NV]; };
 
-__device__ __forceinline__ void load_row(RowVec& r, const float* x, int C, int lane) {
+template <int NV>
+__device__ __forceinline__ void load_row(RowVec<NV>& r, const float* x, int C, int lane) {
     const int nv = C >> 2;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         r.v[k] = i < nv ? ((const float4*)x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
-__device__ __forceinline__ void row_stats(const RowVec& r, int C, int lane, float eps, float& mean, float& rstd) {
+template <int NV>
+__device__ __forceinline__ void row_stats(const RowVec<NV>& r, int C, int lane, float eps, float& mean, float& rstd) {
     const int nv = C >> 2;
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) s += r.v[k].x + r.v[k].y + r.v[k].z + r.v[k].w;
+    for (int k = 0; k < NV; ++k) s += r.v[k].x + r.v[k].y + r.v[k].z + r.v[k].w;
     mean = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         if (lane + 64 * k < nv) {
             const float a = r.v[k].x - mean, b = r.v[k].y - mean, c = r.v[k].z - mean, d = r.v[k].w - mean;
             q += a * a + b * b + c * c + d * d;
@@ -39,6 +43,7 @@ __device__ __forceinline__ void row_stats(const RowVec& r, int C, int lane, floa
 }
 
 // y = (x - mean) * rstd * w + b  ->  bf16
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, const int* __restrict__ count,
                    const float* __restrict__ w, const float* __restrict__ b, bf16* __restrict__ y,
@@ -50,20 +55,20 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
     const int n_valid = count ? *count : M;
     if (row >= n_valid) {     // padded compact rows stay zero
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) ((bf16x4*)(y + (size_t)row * C))[i] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
         }
         return;
     }
     const int src = rowidx ? rowidx[row] : row;
-    RowVec r;
+    RowVec<NV> r;
     load_row(r, x + (size_t)src * C, C, lane);
     float mean, rstd;
     row_stats(r, C, lane, eps, mean, rstd);
     if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         if (i < nv) {
             const float4 ww = ((const float4*)w)[i], bb = ((const float4*)b)[i];
@@ -76,28 +81,31 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
 
 // dx = dres + rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += dy*xhat;  db += dy
 #define LNB_ROWS 32   // rows per block
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ rowidx,
                    const int* __restrict__ count, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                    const float* __restrict__ w, const float* __restrict__ dres, float* __restrict__ dx,
-                   float* __restrict__ dw, float* __restrict__ db, int M, int C) {
+                   float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride) {
     __shared__ float red[2][LN_WAVES][64 * 4];
+    // column sums go to replica (block % nrep): spreads same-address atomic contention (summed once per step)
+    dw += (size_t)(blockIdx.x % nrep) * rep_stride; db += (size_t)(blockIdx.x % nrep) * rep_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
     const int n_valid = count ? min(*count, M) : M;
-    RowVec aw, ab;
+    RowVec<NV> aw, ab;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
+    for (int k = 0; k < NV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
     const int row_end = min((int)(blockIdx.x + 1) * LNB_ROWS, n_valid);
     for (int row = blockIdx.x * LNB_ROWS + wave; row < row_end; row += LN_WAVES) {
         const int xr = rowidx ? rowidx[row] : row;
-        RowVec r;
+        RowVec<NV> r;
         load_row(r, x + (size_t)xr * C, C, lane);
         const float mean = mean_i[row], rstd = rstd_i[row];
-        float4 g[LN_MAXV];
+        float4 g[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
                 const bf16x4 d = ((const bf16x4*)(dy + (size_t)row * C))[i];
@@ -118,7 +126,7 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
         s1 = wave_sum(s1) / C;
         s2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
                 float4 o = make_float4(rstd * (g[k].x - s1 - r.v[k].x * s2), rstd * (g[k].y - s1 - r.v[k].y * s2),
@@ -133,7 +141,7 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
     }
     // cross-wave reduction of the column partials, then one atomic per column per block
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         if (64 * k < nv) {
             __syncthreads();
             ((float4*)red[0][wave])[lane] = aw.v[k];
@@ -160,6 +168,7 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
 }
 
 // acc[i] (+)= layer_norm(x[rowidx[i]])  (no affine)
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, const int* __restrict__ count,
                          float* __restrict__ acc, int first, int Mmax, int C, float eps) {
@@ -171,15 +180,15 @@ void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ ro
     if (row >= *count) {
         if (first)
 #pragma unroll
-            for (int k = 0; k < LN_MAXV; ++k) if (lane + 64 * k < nv) dst[lane + 64 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < NV; ++k) if (lane + 64 * k < nv) dst[lane + 64 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    RowVec r;
+    RowVec<NV> r;
     load_row(r, x + (size_t)rowidx[row] * C, C, lane);
     float mean, rstd;
     row_stats(r, C, lane, eps, mean, rstd);
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         if (i < nv) {
             float4 o = make_float4((r.v[k].x - mean) * rstd, (r.v[k].y - mean) * rstd, (r.v[k].z - mean) * rstd,
@@ -190,6 +199,7 @@ void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ ro
     }
 }
 
+template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ count, float inv_layers, int post_ln,
                             int Mmax, int C, float eps) {
@@ -197,14 +207,14 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= Mmax || row >= *count) return;
     const int nv = C >> 2;
-    RowVec r;
+    RowVec<NV> r;
     load_row(r, acc + (size_t)row * C, C, lane);
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) { r.v[k].x *= inv_layers; r.v[k].y *= inv_layers; r.v[k].z *= inv_layers; r.v[k].w *= inv_layers; }
+    for (int k = 0; k < NV; ++k) { r.v[k].x *= inv_layers; r.v[k].y *= inv_layers; r.v[k].z *= inv_layers; r.v[k].w *= inv_layers; }
     float mean = 0.f, rstd = 1.f;
     if (post_ln) row_stats(r, C, lane, eps, mean, rstd);
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         if (i < nv)
             ((float4*)(acc + (size_t)row * C))[i] = make_float4((r.v[k].x - mean) * rstd, (r.v[k].y - mean) * rstd,
@@ -212,48 +222,72 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     }
 }
 
+#define LN_DISPATCH(KERNEL, C, ...) do { const int _nv = ((C) + 255) / 256; \
+    if (_nv <= 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (_nv == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); \
+    else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
+    else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
+
 static int ln_shape_ok(int M, int C) { return (M > 0 && C > 0 && (C % 4) == 0 && C <= LN_MAXV * 256) ? UVIT_OK : UVIT_ERR_SHAPE; }
 
 int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd, int M, int C,
                        float eps, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, (const int*)nullptr,
+    LN_DISPATCH(ln_fwd_kernel, C, dim3((M + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, (const int*)nullptr,
                        (const int*)nullptr, w, b, (bf16*)y, mean, rstd, M, C, eps);
     return uvit_check_launch();
 }
 int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* count, const float* w, const float* b,
                               void* y, float* mean, float* rstd, int Mmax, int C, float eps, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx, count,
+    LN_DISPATCH(ln_fwd_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx, count,
                        w, b, (bf16*)y, mean, rstd, Mmax, C, eps);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
-                       const float* dres, float* dx, float* dw, float* db, int M, int C, hipStream_t s) {
+                       const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C);
+    LN_DISPATCH(ln_bwd_kernel, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,
                                const float* rstd, const float* w, float* dx, float* dw, float* db, int Mmax, int C,
-                               hipStream_t s) {
+                               int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C);
+    LN_DISPATCH(ln_bwd_kernel, C, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride);
     return uvit_check_launch();
 }
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
                              int C, float eps, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(target_accum_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx,
+    LN_DISPATCH(target_accum_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx,
                        count, acc, first, Mmax, C, eps);
     return uvit_check_launch();
 }
 int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
                                 hipStream_t s) {
     if (ln_shape_ok(Mmax, C) || n_layers <= 0) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(target_finalize_kernel, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, acc,
+    LN_DISPATCH(target_finalize_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, acc,
                        count, 1.0f / n_layers, post_ln, Mmax, C, eps);
+    return uvit_check_launch();
+}
+
+// grads[i] += sum_r rep[r][i]  (replicated column-sum accumulators -> gradient arena), once per step
+__global__ __launch_bounds__(256)
+void reduce_replicas_kernel(const float* __restrict__ rep, float* __restrict__ out, size_t n4, int nrep, size_t stride4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ((const float4*)out)[i];
+        for (int r = 0; r < nrep; ++r) {
+            const float4 b = ((const float4*)rep)[(size_t)r * stride4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        ((float4*)out)[i] = a;
+    }
+}
+int uvit_reduce_replicas_launch(const float* rep, float* out, size_t n, int nrep, size_t stride, hipStream_t s) {
+    if (n % 4 || stride % 4) return UVIT_ERR_SHAPE;
+    size_t g = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, rep, out, n / 4, nrep, stride / 4);
     return uvit_check_launch();
 }

@@ -42,10 +42,12 @@ int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y_b
 int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* count, const float* w, const float* b,
                               void* y_bf16, float* mean, float* rstd, int Mmax, int C, float eps, hipStream_t s);
 int uvit_ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* w,
-                       const float* dres, float* dx, float* dw, float* db, int M, int C, hipStream_t s);
+                       const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride,
+                       hipStream_t s);
 int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* rowidx, const int* count,
                                const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
-                               int Mmax, int C, hipStream_t s);
+                               int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
+int uvit_reduce_replicas_launch(const float* rep, float* out, size_t n, int nrep, size_t stride, hipStream_t s);
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
                              int C, float eps, hipStream_t s);
 int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
@@ -59,8 +61,10 @@ int uvit_relpos_gather_launch(const float* table, const int* index, float* biasP
 int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, float* dtable, int H, int N, int NP,
                                hipStream_t s);
 int uvit_ls_bwd_launch(const float* dx, const void* branch_bf16, const float* gamma, const float* rowscale,
-                       void* dy_bf16, float* dgamma, float* dbias, int M, int C, int tokens, hipStream_t s);
-int uvit_colsum_launch(const void* y_bf16, int ld, int col0, int ncols, int M, float* out, hipStream_t s);
+                       void* dy_bf16, float* dgamma, float* dbias, int M, int C, int tokens, int nrep, size_t rep_stride,
+                       hipStream_t s);
+int uvit_colsum_launch(const void* y_bf16, int ld, int col0, int ncols, int M, float* out, int nrep, size_t rep_stride,
+                       hipStream_t s);
 int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,
                           float* loss, void* dout_bf16, int Mmax, int C, hipStream_t s);
 int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf16, float* dcls, float* dmask_token,
