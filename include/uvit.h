@@ -121,6 +121,9 @@ int uvit_step_begin(uvit_engine* e, const float* images, const int64_t* mask, co
                     uvit_stream stream);
 /* backward of block `layer` (call depth-1 .. 0); its gradients are complete afterwards */
 int uvit_step_backward_layer(uvit_engine* e, int layer, const uvit_step_params* hp, uvit_stream stream);
+/* make `stream` wait until block `layer`'s weight gradients (computed on the engine's second stream) are final:
+ * call on the communication stream before all-reducing that block's bucket */
+int uvit_step_wait_layer_grads(uvit_engine* e, int layer, uvit_stream stream);
 /* token assembly + patch embedding + relative-position table gradients */
 int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream);
 /* clip_grad_norm_ + AdamW (utils.py:375-381) + EMA (engine_for_cyclical.py:182-185) + shadow refresh */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -118,7 +119,7 @@ struct uvit_engine {
     float *meanF, *rstdF, *outputs, *targets;
     float *biasP_s, *biasP_t, *slabs, *delta;
     float *dXa, *dXb;
-    bf16 *dY, *dH, *dLN, *dAttn, *dqkv;
+    bf16 *dY1[2], *dY2[2], *dH[2], *dLN, *dAttn, *dqkv[2];   // [layer parity]: read by the wgrad stream while the next layer runs
     float *dp_scales, *dp_rates;
     float *loss, *gnorm; double* sumsq;
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
@@ -128,6 +129,11 @@ struct uvit_engine {
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
     // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
+    // second stream: teacher forward beside student forward; wgrad GEMMs beside the dgrad chain
+    bool dual = true;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_teacher = nullptr, ev_x[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_wdone[UVIT_MAX_DEPTH] = {};
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
     size_t prof_used = 0;
@@ -170,8 +176,11 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->slabs = b.take<float>(bias_n * e->nchunk);
     e->delta = b.take<float>((size_t)e->B * e->H * e->N);
     e->dXa = b.take<float>(Mp * C); e->dXb = b.take<float>(Mp * C);
-    e->dY = b.take<bf16>(Mp * C); e->dH = b.take<bf16>(Mp * Hd); e->dLN = b.take<bf16>(Mp * C);
-    e->dAttn = b.take<bf16>(Mp * C); e->dqkv = b.take<bf16>(Mp * 3 * C);
+    for (int k = 0; k < 2; ++k) {
+        e->dY1[k] = b.take<bf16>(Mp * C); e->dY2[k] = b.take<bf16>(Mp * C); e->dH[k] = b.take<bf16>(Mp * Hd);
+        e->dqkv[k] = b.take<bf16>(Mp * 3 * C);
+    }
+    e->dLN = b.take<bf16>(Mp * C); e->dAttn = b.take<bf16>(Mp * C);
     e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->B); e->dp_rates = b.take<float>(c.depth);
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->tdesc = b.take<TransposeDesc>(5 * c.depth + 2);
@@ -192,6 +201,7 @@ static void fill_dims(uvit_engine* e) {
     e->n_nd = tmp_lo.n_total - tmp_lo.n_decay;
 }
 
+extern "C" void uvit_engine_destroy(uvit_engine* e);
 extern "C" int uvit_version(void) { return UVIT_VERSION; }
 
 extern "C" int uvit_layout_count(const uvit_config* cfg) {
@@ -261,6 +271,16 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
         hipMemcpyAsync(e->tdesc, td.data(), td.size() * sizeof(TransposeDesc), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
     e->slab_started = false; e->last_dropout = false; e->last_seed = 0; e->last_it = 0;
+    {
+        const char* env = getenv("UVIT_SINGLE_STREAM");
+        e->dual = !(env && env[0] == '1');
+        bool ok = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess;
+        auto mk = [&](hipEvent_t* ev) { ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
+        mk(&e->ev_fork); mk(&e->ev_teacher);
+        for (int i = 0; i < 4; ++i) mk(&e->ev_x[i]);
+        for (int i = 0; i < cfg->depth; ++i) mk(&e->ev_wdone[i]);
+        if (!ok) { uvit_engine_destroy(e); return fail(UVIT_ERR_LAUNCH); }
+    }
     if (err_out) *err_out = UVIT_OK;
     return e;
 }
@@ -268,6 +288,11 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
 extern "C" void uvit_engine_destroy(uvit_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_teacher) (void)hipEventDestroy(e->ev_teacher);
+    for (int i = 0; i < 4; ++i) if (e->ev_x[i]) (void)hipEventDestroy(e->ev_x[i]);
+    for (int i = 0; i < UVIT_MAX_DEPTH; ++i) if (e->ev_wdone[i]) (void)hipEventDestroy(e->ev_wdone[i]);
     delete e;
 }
 
@@ -457,12 +482,17 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     e->slab_started = false;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
-    // teacher (EMA weights, eval mode, no grad): engine_for_cyclical.py:68-122
-    CHECK(run_forward(e, 1, images, nullptr, Bc, false, false, 0, 0, hp, false, s));
-    // student: engine_for_cyclical.py:124-128
+    CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
+    // teacher (EMA weights, eval mode, no grad: engine_for_cyclical.py:68-122) runs on the second stream,
+    // beside the student forward (engine_for_cyclical.py:124-128); they share only read-only inputs
+    hipStream_t ts = e->dual ? e->aux : s;
+    if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }
+    CHECK(run_forward(e, 1, images, nullptr, Bc, false, false, 0, 0, hp, true, ts));
+    if (e->dual) HIPCHECK(hipEventRecord(e->ev_teacher, ts));
     CHECK(run_forward(e, 0, images, mask, Bc, true, hp->train_dropout != 0, hp->seed, hp->it, nullptr, true, s));
     Weights w{e->buf.params, (const bf16*)e->buf.params_bf16};
     CHECK(head_forward(e, w, Bc, false, e->outputs, s));
+    if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_teacher, 0));
     // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163
     const float ls = hp->loss_scale == -1.0f ? 1.0f : hp->loss_scale;
     CHECK(uvit_smooth_l1_launch(e->outputs, e->targets, e->count, hp->l1_beta, hp->l2_loss, ls, e->loss, e->dout, BP, C, s));
@@ -494,31 +524,49 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     const float* dp1 = dp_on ? e->dp_scales + (size_t)(2 * l) * e->B : nullptr;
     const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * e->B : nullptr;
     const float pdrop = e->last_dropout ? e->cfg.attn_drop_rate : 0.f;
+    // wgrad GEMMs + bias column sums go to the second stream; the dgrad chain stays on `s`.  The
+    // gradient buffers they read are double-buffered by layer parity; before reusing a parity the
+    // main stream waits for the wgrad work of layer l+2.
+    const int par = l & 1;
+    hipStream_t ws = e->dual ? e->aux : s;
+    auto handoff = [&](int k) -> int {          // work enqueued on `s` so far is visible to the wgrad stream
+        if (!e->dual) return UVIT_OK;
+        HIPCHECK(hipEventRecord(e->ev_x[k], s));
+        HIPCHECK(hipStreamWaitEvent(ws, e->ev_x[k], 0));
+        return UVIT_OK;
+    };
+    if (e->dual && l + 2 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 2], 0));
+    bf16 *dY1 = e->dY1[par], *dY2 = e->dY2[par], *dH = e->dH[par], *dqkv = e->dqkv[par];
     // --- MLP branch: x_out = x_mid + dp2 * gamma2 * (fc2(gelu(fc1(ln2(x_mid)))))
-    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, e->dY, RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dY, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, 1, s));
-    GemmEpi d1; d1.out = e->dH; d1.aux = a.h; d1.ldo = Hd;
-    CHECK(uvit_gemm_nt_launch(EPI_DGELU, e->dY, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
-    CHECK(uvit_colsum_launch(e->dH, Hd, 0, Hd, M, RP(o.fc1b), NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, 1, s));
+    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, dY1, RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
+    CHECK(handoff(0));
+    CHECK(uvit_gemm_tn_launch(dY1, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+    GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
+    CHECK(uvit_gemm_nt_launch(EPI_DGELU, dY1, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
+    CHECK(handoff(1));
+    CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, M, RP(o.fc1b), NREP, e->n_nd, ws));
+    CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
     CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), M, C, NREP, e->n_nd, s));
     // --- attention branch: x_mid = x_in + dp1 * gamma1 * proj(attn(ln1(x_in)))
-    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, e->dY, RP(o.g1), RP(o.projb), M, C, e->N, NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dY, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, s));
+    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, dY2, RP(o.g1), RP(o.projb), M, C, e->N, NREP, e->n_nd, s));
+    CHECK(handoff(2));
+    CHECK(uvit_gemm_tn_launch(dY2, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, ws));
     GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dY, wt + o.projw, M, C, C, C, C, &d3, s));
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2, wt + o.projw, M, C, C, C, C, &d3, s));
     const float* biasP = e->cfg.use_shared_rel_pos_bias ? e->biasP_s : nullptr;
-    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, e->dqkv, biasP ? e->slabs : nullptr,
+    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, biasP ? e->slabs : nullptr,
                                e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed,
                                (uint32_t)l, s));
     e->slab_started = true;
-    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 0, C, M, RP(o.qb), NREP, e->n_nd, s));
-    CHECK(uvit_colsum_launch(e->dqkv, 3 * C, 2 * C, C, M, RP(o.vb), NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, s));
+    CHECK(handoff(3));
+    CHECK(uvit_colsum_launch(dqkv, 3 * C, 0, C, M, RP(o.qb), NREP, e->n_nd, ws));
+    CHECK(uvit_colsum_launch(dqkv, 3 * C, 2 * C, C, M, RP(o.vb), NREP, e->n_nd, ws));
+    CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
+    if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
     CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), M, C, NREP, e->n_nd, s));
     return UVIT_OK;
 }
@@ -535,8 +583,15 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, 1, s));
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
+    if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed
     // fold the replicated column-sum accumulators into the no-decay gradients
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
+    return UVIT_OK;
+}
+
+extern "C" int uvit_step_wait_layer_grads(uvit_engine* e, int layer, uvit_stream stream) {
+    if (!e || layer < 0 || layer >= e->cfg.depth) return UVIT_ERR_ARG;
+    if (e->dual) HIPCHECK(hipStreamWaitEvent((hipStream_t)stream, e->ev_wdone[layer], 0));
     return UVIT_OK;
 }
 

@@ -47,7 +47,7 @@ class GradReducer:
         self.small_range = (model._n_decay, model._arena.numel())      # every no-decay tensor, one message
         self.pending = []
 
-    def reduce(self, grads, rng):
+    def reduce(self, grads, rng, engine=None, layer=None):
         if not self.enabled or rng[1] <= rng[0]:
             return
         view = grads[rng[0]:rng[1]]
@@ -55,6 +55,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm.wait_event(ev)
+            if layer is not None:      # the block's wgrads run on the engine's second stream
+                check(lib().uvit_step_wait_layer_grads(engine.h, layer, C.c_void_p(self.comm.cuda_stream)), "wait_layer_grads")
             with torch.cuda.stream(self.comm):
                 self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
         else:
@@ -82,7 +84,7 @@ def native_step(engine, reducer, samples, mask, hp):
     reducer.reduce(g, reducer.head_range)
     for l in range(engine.model.depth - 1, -1, -1):
         check(L.uvit_step_backward_layer(h, l, hp_ref, s), "uvit_step_backward_layer")
-        reducer.reduce(g, reducer.layer_ranges[l])
+        reducer.reduce(g, reducer.layer_ranges[l], engine, l)
     check(L.uvit_step_backward_embed(h, s), "uvit_step_backward_embed")
     reducer.reduce(g, reducer.embed_range)
     reducer.reduce(g, reducer.small_range)

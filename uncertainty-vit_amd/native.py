@@ -75,6 +75,7 @@ _PROTOTYPES = {
     "uvit_step_begin": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_step_backward_layer": (_i, [_vp, _i, _vp, _vp]),
     "uvit_step_backward_embed": (_i, [_vp, _vp]),
+    "uvit_step_wait_layer_grads": (_i, [_vp, _i, _vp]),
     "uvit_step_update": (_i, [_vp, _vp, _vp]),
     "uvit_train_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_engine_read_stats": (_i, [_vp, _vp, _vp]),
