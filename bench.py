@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE = 140.698        # student fwd + bwd + teacher fwd, algorithmic 2MNK
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+# fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
+ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
+TRAFFIC_BYTES = None             # PMC-measured HBM bytes per launch (profiles/round1_pmc_fc1.txt); filled when collected
 
 
 def synthetic_batch(B, seed, device):
@@ -63,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +116,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.single_stream:
+        check(L.uvit_engine_set_streams(engine.h, 0), "set_streams")
     for i in range(a.warmup):
         step(i)
     fence()
+    # timed region: K steps.  The dominant kernel's launches are bracketed with HIP events on their own stream;
+    # in the default two-stream schedule other kernels share the GPU with it, so that duration is "overlapped".
     check(L.uvit_engine_profile(engine.h, 1, 4096), "profile on")
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -124,6 +132,17 @@ def main():
     check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
     tot, n, fl = C.c_double(), C.c_int(), C.c_double()
     check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
+    ov_ms = tot.value / max(n.value, 1)
+    if not a.single_stream:
+        # the same kernel alone on the GPU: a few extra single-stream steps right after the timed region
+        check(L.uvit_engine_set_streams(engine.h, 0), "set_streams")
+        check(L.uvit_engine_profile(engine.h, 1, 4096), "profile on")
+        for i in range(3):
+            step(a.warmup + a.steps + i)
+        fence()
+        check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
+        check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
+        check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
     stats = torch.zeros(2).pin_memory()
     check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -147,8 +166,11 @@ def main():
                        "final_loss": round(float(stats[0]), 5)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": None,
-                         "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4)},
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": TRAFFIC_BYTES,
+                         "algorithmic_bytes": ALGO_BYTES, "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4),
+                         "measured": "HIP events on the launch stream; " + ("timed region, single stream" if a.single_stream else
+                                     "3 single-stream steps right after the timed region (kernel alone on the GPU)"),
+                         "avg_launch_ms_in_timed_region_overlapped": round(ov_ms, 4)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

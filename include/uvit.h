@@ -131,6 +131,10 @@ int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream str
 /* all of the above on one stream (single-GPU fast path) */
 int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
                     uvit_stream stream);
+/* dual = 1 (default): teacher forward and the wgrad GEMMs run on an internal second HIP stream beside the
+ * caller's stream; dual = 0: everything on the caller's stream (used to time one kernel in isolation).
+ * Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
+int uvit_engine_set_streams(uvit_engine* e, int dual);
 /* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
  * fused bias+GELU, gemm_nt_kernel<EPI_GELU>) with HIP events on the stream it runs on.
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */

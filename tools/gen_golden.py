@@ -177,6 +177,25 @@ def gen_schedules():
     print("wrote schedules")
 
 
+def gen_cli_defaults():
+    """Flag names / defaults of the reference CLI: exec the get_args() definition of run_cyclical.py:36-284
+    (the module itself cannot be imported: datasets.py needs the missing cifar_semi)."""
+    import json
+    src = open(os.path.join(ref_harness.REFERENCE, "run_cyclical.py")).read()
+    body = src[src.index("def get_args():"):src.index("def get_model(args):")]
+    ns = {"argparse": argparse}
+    exec(compile(body, "run_cyclical.get_args", "exec"), ns)
+    old = sys.argv
+    sys.argv = ["run_cyclical.py"]
+    try:
+        a = ns["get_args"]()
+    finally:
+        sys.argv = old
+    with open(os.path.join(OUT, "cli_defaults.json"), "w") as f:
+        json.dump(vars(a), f, indent=1, sort_keys=True)
+    print("wrote cli defaults:", len(vars(a)), "flags")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -193,6 +212,8 @@ def main():
         gen_vitb_spot(mc)
     if a.only in (None, "sched"):
         gen_schedules()
+    if a.only in (None, "cli"):
+        gen_cli_defaults()
 
 
 if __name__ == "__main__":

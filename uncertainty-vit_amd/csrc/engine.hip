@@ -296,6 +296,12 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     delete e;
 }
 
+extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
+    if (!e) return UVIT_ERR_ARG;
+    e->dual = dual != 0;
+    return UVIT_OK;
+}
+
 extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches) {
     if (!e) return UVIT_ERR_ARG;
     if (enable && e->prof_ev.empty()) {
