@@ -437,17 +437,23 @@ def _mix32(x: np.ndarray) -> np.ndarray:
     return x
 
 
-def attn_keep_mask(seed: int, layer: int, B: int, H: int, N: int, p_drop: float) -> Tensor:
-    """(B,H,N,N) multiplier, 0 or 1/(1-p): element (b,h,i,j) is kept when
-    hash(seed, layer, ((b*H+h)*N+i)*N+j) >= p * 2^32.  Mirrors `uvit_keep` in csrc/common.h."""
+def attn_keep_mask(seed: int, layer: int, B: int, H: int, N: int, p_drop: float, NP: int = 208) -> Tensor:
+    """(B,H,N,N) multiplier, 0 or 1/(1-p).  Mirrors `keep4` / `keep1` in csrc/attention.hip: one 32-bit hash per
+    (query row, key pair), pair index = ((b*H+h)*N + q) * (NP/2) + (key >> 1); key takes the low (even key) or
+    high (odd key) 16 bits and is kept when that half >= int(p * 65536)."""
     if p_drop <= 0:
         return torch.ones(B, H, N, N)
     with np.errstate(over="ignore"):
-        idx = np.arange(B * H * N * N, dtype=np.uint64).astype(np.uint32)
-        key = _mix32(np.uint32(seed) ^ (np.uint32(layer + 1) * np.uint32(0x9E3779B9)))
-        r = _mix32(idx ^ key)
-    thr = np.uint32(min(int(p_drop * 4294967296.0), 0xFFFFFFFF))
-    keep = (r >= thr).astype(np.float32) / np.float32(1.0 - p_drop)
+        key32 = _mix32(np.uint32(seed) ^ (np.uint32(layer + 1) * np.uint32(0x9E3779B9)))
+        rows = (np.arange(B * H * N, dtype=np.uint64) * np.uint64(NP // 2)).astype(np.uint32)
+        pairs = (rows[:, None] + np.arange((N + 1) // 2, dtype=np.uint32)[None, :]).astype(np.uint32)
+        x = ((pairs ^ key32) * np.uint32(0x9E3779B1)).astype(np.uint32)
+        x ^= x >> np.uint32(15)
+        x = (x * np.uint32(0x85EBCA77)).astype(np.uint32)
+        x ^= x >> np.uint32(13)
+    halves = np.stack([x & np.uint32(0xFFFF), x >> np.uint32(16)], axis=-1).reshape(B * H * N, -1)[:, :N]
+    thr = min(int(p_drop * 65536.0), 65535)
+    keep = (halves >= thr).astype(np.float32) / np.float32(1.0 - p_drop)
     return torch.from_numpy(keep.reshape(B, H, N, N))
 
 

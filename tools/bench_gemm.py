@@ -67,10 +67,15 @@ if __name__ == "__main__":
         for K in (128, 256, 768, 1536, 3072, 6144):
             us, tf = time_nt(0, M, N, K)
             print(f"N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
-    print("== NT: step shapes ==")
+    print("== NT: step shapes, variants 0 (128x128) / 1 (256x256) / 2 (128x256 x2 per CU) ==")
     for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
-        us, tf = time_nt(mode, M, N, K)
-        print(f"{names[mode]:6s} N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
+        row = []
+        for v in (0, 1, 2):
+            L.uvit_set_gemm_variant(v)
+            us, tf = time_nt(mode, M, N, K)
+            row.append(f"v{v}: {us:7.1f} us {tf:6.1f} TF/s")
+        print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
+    L.uvit_set_gemm_variant(3)
     print("== NT: square references ==")
     for n in (4096, 8192):
         us, tf = time_nt(0, n, n, n, iters=5)

@@ -1,3 +1,5 @@
+// (units) biasP is the relative-position bias times log2(e) with -1e30 in padded key columns; LSE is kept in
+// log2 units -- both are private to these kernels (uvit_relpos_gather_launch builds biasP).
 // Fused multi-head attention with shared relative-position bias and attention dropout for
 // ViT token counts (N <= 208, head_dim 64), gfx950.  Scores never touch HBM.
 //
@@ -56,6 +58,27 @@ __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
     return v;
 }
 
+// Dropout: one 32-bit hash per (query row, key pair); each key takes a 16-bit half and is kept when
+// half >= round(p * 65536).  pair index = (bh*N + q) * (NP/2) + (key >> 1).  Mirrored by
+// oracle/vit_oracle.py::attn_keep_mask.
+__device__ __forceinline__ uint32_t pair_hash(uint32_t key32, uint32_t pidx) {
+    uint32_t x = (pidx ^ key32) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x;
+}
+// keep flags of the 4 consecutive keys kbase..kbase+3 (kbase % 4 == 0) of one query row
+__device__ __forceinline__ void keep4(uint32_t key32, uint32_t rowpair, int kbase, uint32_t thr16, bool (&k)[4]) {
+    const uint32_t h0 = pair_hash(key32, rowpair + (kbase >> 1)), h1 = pair_hash(key32, rowpair + (kbase >> 1) + 1);
+    k[0] = (h0 & 0xFFFFu) >= thr16; k[1] = (h0 >> 16) >= thr16;
+    k[2] = (h1 & 0xFFFFu) >= thr16; k[3] = (h1 >> 16) >= thr16;
+}
+__device__ __forceinline__ bool keep1(uint32_t key32, uint32_t rowpair, int key, uint32_t thr16) {
+    const uint32_t h = pair_hash(key32, rowpair + (key >> 1));
+    return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
+#define LOG2E 1.4426950408889634f
+#define NEG_BIG (-1e30f)
+
 __device__ __forceinline__ float group_sum4(float v) {   // sum over the 4 lane groups (lanes l, l^16, l^32, l^48)
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -70,8 +93,8 @@ __device__ __forceinline__ float group_max4(float v) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64)
+template <int NW, bool HAS_BIAS>
+__global__ __launch_bounds__(NW * 64, 4)      // two 7-wave workgroups per CU need <= 128 VGPRs
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ biasP, bf16* __restrict__ out,
                      float* __restrict__ lse, int H, int N, int NP, float scale, uint32_t drop_thr,
                      float inv_keep, uint32_t drop_key) {
@@ -95,21 +118,28 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
         bf16x8 qf[2];
         qf[0] = *(const bf16x8*)(base + (size_t)qr * ld + g * 8);
         qf[1] = *(const bf16x8*)(base + (size_t)qr * ld + 32 + g * 8);
+        // scores in log2 units: s' = (q.k) * scale*log2(e) + biasP   (biasP is pre-multiplied by log2(e) and holds
+        // -1e30 in padded key columns, so padded keys vanish in the softmax without per-element selects)
         float s[NT_MAX][4];
-        float mx = -1e30f;
+        float mx = NEG_BIG;
+        const float c = scale * LOG2E;
 #pragma unroll
         for (int t = 0; t < NT_MAX; ++t) {
             if (t < nt) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, g), qf[0], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, 4 + g), qf[1], a, 0, 0, 0);
-                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (biasP) bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                float bb[4];
+                if constexpr (HAS_BIAS) {
+                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                    bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + 4 * g + r;
-                    const float v = key < N ? a[r] * scale + bb[r] : -1e30f;
+                    const float v = a[r] * c + bb[r];
                     s[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -125,34 +155,35 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(s[t][r] - mx);
+                    const float p = __builtin_amdgcn_exp2f(s[t][r] - mx);
                     s[t][r] = p;
                     sum += p;
                 }
             }
         }
         sum = group_sum4(sum);
-        if (g == 0 && q < N) lse[(size_t)bh * N + q] = mx + __logf(sum);
-        if (drop_thr) {
-            const uint32_t rowidx = ((uint32_t)bh * N + q) * N;
-#pragma unroll
-            for (int t = 0; t < NT_MAX; ++t) {
-                if (t < nt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (!uvit_keep(drop_key, rowidx + t * 16 + 4 * g + r, drop_thr)) s[t][r] = 0.f;
-                }
-            }
-        }
+        if (g == 0 && q < N) lse[(size_t)bh * N + q] = mx + __builtin_amdgcn_logf(sum);      // log2 units
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
 #pragma unroll
         for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
             if (ks < nt2) {
                 const int t0 = 2 * ks, t1 = 2 * ks + 1;
-                const bf16x8 pf = pack8(s[t0], t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0] : zero4);
+                float pa[4], pb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pa[r] = s[t0][r]; pb[r] = t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0][r] : 0.f; }
+                if (drop_thr) {        // dropout applied while packing P: short live ranges for the hash values
+                    bool k4[4];
+                    keep4(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pa[r] = k4[r] ? pa[r] : 0.f;
+                    keep4(drop_key, rowpair, t1 * 16 + 4 * g, drop_thr, k4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb[r] = k4[r] ? pb[r] : 0.f;
+                }
+                const bf16x8 pf = pack8(pa, pb);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const bf16x8 vf = col_frag(vimg, t0 * 16, t1 * 16, dt * 16, lane);
@@ -175,6 +206,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
 // ------------------------------------------------------------------------------------------
 // backward, query-owned: dQ, delta, and the rel-pos-bias gradient summed over a batch chunk
 // ------------------------------------------------------------------------------------------
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(BWD_WAVES * 64)
 void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                         const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
@@ -227,7 +259,8 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
         dl = group_sum4(dl);
         const float lse_q = lse[(size_t)bh * N + qr];
         if (g == 0 && q < N) delta[(size_t)bh * N + q] = dl;
-        const uint32_t rowidx = ((uint32_t)bh * N + q) * N;
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+        const float c = scale * LOG2E;
 
         f32x4 dq[4];
 #pragma unroll
@@ -248,19 +281,24 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], s, 0, 0, 0);
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vimg, t * 16 + li, kk * 4 + g), dof[kk], dp, 0, 0, 0);
                         }
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (biasP) bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                        float bb[4];
+                        if constexpr (HAS_BIAS) {
+                            const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                            bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
+                        }
+                        bool k4[4] = {true, true, true, true};
+                        if (drop_thr) keep4(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int key = t * 16 + 4 * g + r;
-                            float p = 0.f;
-                            if (key < N && q < N) p = __expf(s[r] * scale + bb[r] - lse_q);
-                            float dmul = 1.0f;
-                            if (drop_thr) dmul = uvit_keep(drop_key, rowidx + key, drop_thr) ? inv_keep : 0.f;
-                            const float ds = p * (dmul * dp[r] - dl);
+                            // padded keys: bias = -1e30 -> p = 0; padded query lanes are never stored / read
+                            const float p = __builtin_amdgcn_exp2f(s[r] * c + bb[r] - lse_q);
+                            const float dpv = k4[r] ? dp[r] * inv_keep : 0.f;
+                            const float ds = p * (dpv - dl);
                             dsv[tt][r] = ds;
-                            if (t < NT_MAX) dbacc[t < NT_MAX ? t : 0][r] += ds;
+                            dbacc[t < NT_MAX ? t : 0][r] += ds;
                         }
                     }
                 }
@@ -301,6 +339,7 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
 // ------------------------------------------------------------------------------------------
 // backward, key-owned: dK, dV
 // ------------------------------------------------------------------------------------------
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(BWD_WAVES * 64)
 void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ biasP,
                          const float* __restrict__ lse, const float* __restrict__ delta, bf16* __restrict__ dqkv,
@@ -336,6 +375,7 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
         kf[kk] = *(const bf16x8*)(base + C + (size_t)kr * ld + kk * 32 + g * 8);
         vf[kk] = *(const bf16x8*)(base + 2 * C + (size_t)kr * ld + kk * 32 + g * 8);
     }
+    const float c = scale * LOG2E;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -357,14 +397,14 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // padded query rows have zero Q / dO / delta / lse and a zero bias row: p stays finite and its
+                    // products vanish; padded keys (bias -1e30) give p = 0
                     const int q = qt * 16 + 4 * g + r;
-                    float p = 0.f;
-                    if (q < N && key < N) {
-                        const float bv = biasP ? biasP[((size_t)h * NP + q) * NP + key] : 0.f;
-                        p = __expf(s[r] * scale + bv - lse_s[q]);
-                    }
+                    float bv;
+                    if constexpr (HAS_BIAS) bv = biasP[((size_t)h * NP + q) * NP + key]; else bv = key < N ? 0.f : NEG_BIG;
+                    const float p = __builtin_amdgcn_exp2f(s[r] * c + bv - lse_s[q]);
                     float dmul = 1.0f;
-                    if (drop_thr) dmul = uvit_keep(drop_key, ((uint32_t)bh * N + q) * N + key, drop_thr) ? inv_keep : 0.f;
+                    if (drop_thr) dmul = keep1(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), key, drop_thr) ? inv_keep : 0.f;
                     pdv[tt][r] = p * dmul;
                     dsv[tt][r] = p * (dmul * dp[r] - dl_s[q]);
                 }
@@ -399,9 +439,12 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
 static bool g_attn_attr = false;
 static void attn_init_once() {
     if (g_attn_attr) return;
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 2 * ROWS_PAD * 4);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 2 * ROWS_PAD * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 2 * ROWS_PAD * 4);
     g_attn_attr = true;
 }
 
@@ -414,10 +457,12 @@ int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* 
                          float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
     int rc = attn_check(B, H, N, HD); if (rc) return rc;
     attn_init_once();
-    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold(p_drop) : 0u;
+    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    hipLaunchKernelGGL(attn_fwd_kernel<FWD_WAVES>, dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
-                       biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer));
+    if (biasP) hipLaunchKernelGGL((attn_fwd_kernel<FWD_WAVES, true>), dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
+                                  biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer));
+    else hipLaunchKernelGGL((attn_fwd_kernel<FWD_WAVES, false>), dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
+                            biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer));
     return uvit_check_launch();
 }
 
@@ -427,17 +472,19 @@ int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, co
     int rc = attn_check(B, H, N, HD); if (rc) return rc;
     if (chunk <= 0) return UVIT_ERR_ARG;
     attn_init_once();
-    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold(p_drop) : 0u;
+    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t key = uvit_layer_key(seed, layer);
     const int nt = (N + 15) / 16, nhalf = nt > BWD_WAVES ? 2 : 1;
     const int nchunk = (B + chunk - 1) / chunk;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(H * nchunk * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES, s,
-                       (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, biasP, lse, delta, (bf16*)dqkv,
-                       dbias_slab, accumulate_slab, B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key);
+#define DQ_ARGS dim3(H * nchunk * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, \
+        biasP, lse, delta, (bf16*)dqkv, dbias_slab, accumulate_slab, B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key
+    if (biasP) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, DQ_ARGS); else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, DQ_ARGS);
+#undef DQ_ARGS
     rc = uvit_check_launch(); if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES + 2 * ROWS_PAD * 4, s,
-                       (const bf16*)qkv, (const bf16*)d_o, biasP, lse, delta, (bf16*)dqkv, H, N, NP, nhalf, scale,
-                       thr, inv_keep, key);
+#define DKV_ARGS dim3(B * H * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES + 2 * ROWS_PAD * 4, s, (const bf16*)qkv, (const bf16*)d_o, \
+        biasP, lse, delta, (bf16*)dqkv, H, N, NP, nhalf, scale, thr, inv_keep, key
+    if (biasP) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, DKV_ARGS); else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, DKV_ARGS);
+#undef DKV_ARGS
     return uvit_check_launch();
 }

@@ -39,6 +39,10 @@ __host__ __device__ __forceinline__ uint32_t uvit_drop_threshold(float p) {
     double t = (double)p * 4294967296.0;
     return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
+__host__ __device__ __forceinline__ uint32_t uvit_drop_threshold16(float p) {
+    const double t = (double)p * 65536.0;
+    return t >= 65535.0 ? 65535u : (uint32_t)t;
+}
 // element index idx = ((b*H+h)*N+i)*N+j (mod 2^32); kept when hash >= threshold
 __device__ __forceinline__ bool uvit_keep(uint32_t key, uint32_t idx, uint32_t thr) {
     return uvit_hash32(idx ^ key) >= thr;

@@ -57,13 +57,18 @@ __global__ void set_cls_kernel(float* __restrict__ x, const float* __restrict__ 
     if (i < B * C) { const int b = i / C, c = i - b * C; x[(size_t)b * N * C + c] = cls[c]; }
 }
 
-// biasP[h][q][k] = table[index[q*N+k]][h]; padded to NP x NP with zeros (modeling_finetune.py:359-364)
+// biasP[h][q][k] = table[index[q*N+k]][h] * log2(e)  (modeling_finetune.py:359-364) in the padded NP x NP layout
+// the attention kernels read: padded key columns hold -1e30 (vanish in the softmax), padded query rows 0.
+// table == nullptr (no relative position bias) gives the pure padding mask.
 __global__ void relpos_gather_kernel(const float* __restrict__ table, const int* __restrict__ index,
                                      float* __restrict__ biasP, int H, int N, int NP) {
     const size_t total = (size_t)H * NP * NP;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = i % NP, q = (i / NP) % NP, h = i / ((size_t)NP * NP);
-        biasP[i] = (q < N && k < N) ? table[(size_t)index[q * N + k] * H + h] : 0.f;
+        float v = 0.f;
+        if (k >= N) v = -1e30f;
+        else if (q < N && table) v = table[(size_t)index[q * N + k] * H + h] * 1.4426950408889634f;
+        biasP[i] = v;
     }
 }
 

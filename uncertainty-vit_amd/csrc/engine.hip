@@ -296,6 +296,8 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     delete e;
 }
 
+extern "C" int uvit_set_gemm_variant(int v) { if (v < 0 || v > 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
+
 extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
     if (!e) return UVIT_ERR_ARG;
     e->dual = dual != 0;
@@ -380,11 +382,9 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
     const bool teacher = which == 1;
     Weights w{teacher ? e->buf.ema : e->buf.params, (const bf16*)(teacher ? e->buf.ema_bf16 : e->buf.params_bf16)};
     if (!cols_ready) CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
-    float* biasP = nullptr;
-    if (e->cfg.use_shared_rel_pos_bias) {
-        biasP = teacher ? e->biasP_t : e->biasP_s;
-        CHECK(uvit_relpos_gather_launch(w.f + e->lo.relt, e->buf.rel_index, biasP, e->H, e->N, e->NP, s));
-    }
+    float* biasP = teacher ? e->biasP_t : e->biasP_s;
+    CHECK(uvit_relpos_gather_launch(e->cfg.use_shared_rel_pos_bias ? w.f + e->lo.relt : nullptr, e->buf.rel_index, biasP,
+                                    e->H, e->N, e->NP, s));
     const bool dp_on = dropout && !teacher && e->cfg.drop_path_rate > 0.f;
     const float pdrop = (dropout && !teacher) ? e->cfg.attn_drop_rate : 0.f;
     if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, Bc, seed, it, s));
@@ -561,8 +561,8 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     CHECK(uvit_gemm_tn_launch(dY2, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, ws));
     GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2, wt + o.projw, M, C, C, C, C, &d3, s));
-    const float* biasP = e->cfg.use_shared_rel_pos_bias ? e->biasP_s : nullptr;
-    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, biasP ? e->slabs : nullptr,
+    const float* biasP = e->biasP_s;
+    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr,
                                e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed,
                                (uint32_t)l, s));
     e->slab_started = true;

@@ -239,8 +239,14 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = N / T_BN, tiles_m = (M + T_BM - 1) / T_BM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // tile order: XCD-contiguous chunks (T1), inside them N-groups of <= 6 column tiles walked for every
+    // row tile: one group's W panels (6 x 384 KiB at K = 768) stay resident in the XCD's 4 MiB L2 beside
+    // the streaming A panels instead of the whole W being re-fetched every tile round (PMC: profiles/).
+    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
+    int tn0 = 0;
+    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
+    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
     const int m0 = tm * T_BM, n0 = tn * T_BN;
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
@@ -359,6 +365,108 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
                 for (int nt = 0; nt < 2; ++nt)
                     epilogue4<MODE>(epi, m, n0 + nq * 128 + wn * 32 + nt * 16 + 4 * g, cv[nq][nt], acc[mq][nq][mt][nt]);
         }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, two workgroups per CU: 128x256 block tile, BK = 32, 4 waves (1 M x 4 N, 128x64 each),
+// 3-stage LDS ring of 24 KiB stages (72 KiB -> two resident workgroups per CU).  Loads run two K-tiles
+// ahead behind a counted vmcnt, one barrier per K-tile.  The two co-resident workgroups are
+// independent, so one's HBM-bound epilogue (and its tile-quantisation tail) overlaps the other's
+// MFMA loop -- which the one-workgroup-per-CU 256x256 kernel cannot do at K = 768.
+// LDS image: [rows][32 k] bf16 = 64-B rows, 16-B chunk c of row r stored at chunk c ^ (-(r>>2) & 3):
+// conflict-free for the ds_read_b128 lane groups (4 rows share a 256-B bank row).
+// ------------------------------------------------------------------------------------------
+#define P_BM 128
+#define P_BN 256
+#define P_BK 32
+#define P_THREADS 256
+#define P_STAGE_A (P_BM * P_BK * 2)                 // 8 KiB
+#define P_STAGE (P_STAGE_A + P_BN * P_BK * 2)       // 24 KiB
+#define P_LDS_BYTES (3 * P_STAGE)                   // 72 KiB
+
+template <int MODE>
+__global__ __launch_bounds__(P_THREADS, 2)
+void gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
+                     int lda, int ldw, GemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = N / P_BN, tiles_m = (M + P_BM - 1) / P_BM;
+    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
+    int tn0 = 0;
+    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
+    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
+    const int m0 = tm * P_BM, n0 = tn * P_BN;
+    const int g = lane >> 4, li = lane & 15;
+
+    // loader: a wave-instruction covers 16 rows x 64 B.  A = 8 instructions (2 per wave), W = 16 (4 per wave)
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);          // row>>2 & 3 == lane>>4 (instruction rows start at a multiple of 16)
+    const bf16* a_src[2];
+    const bf16* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int r = m0 + (j * 4 + wave) * 16 + srow; r = r < M ? r : M - 1;
+        a_src[j] = A + (size_t)r * lda + schunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w_src[j] = W + (size_t)(n0 + (j * 4 + wave) * 16 + srow) * ldw + schunk * 8;
+    const int nk = K / P_BK;
+    auto issue = [&](int t) {
+        if (t < nk) {
+            char* st = smem + (t % 3) * P_STAGE;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(a_src[j] + (size_t)t * P_BK, st + (j * 4 + wave) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16(w_src[j] + (size_t)t * P_BK, st + P_STAGE_A + (j * 4 + wave) * 1024);
+        }
+    };
+
+    // fragment address inside a stage: row*64 + ((g ^ (-(row>>2) & 3)) << 4); tile rows = 16*mt + li
+    const int fsw = (g ^ ((-(li >> 2)) & 3)) << 4;
+    const int a_off = li * 64 + fsw;
+    const int b_off = P_STAGE_A + (wave * 64 + li) * 64 + fsw;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    issue(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) VM_WAIT(6); else VM_WAIT(0);        // K-tile t landed (tile t+1's 6 loads may still fly)
+        RAW_BARRIER();                                       // ... for every wave; stage (t+2)%3 is no longer read
+        issue(t + 2);
+        const char* st = smem + (t % 3) * P_STAGE;
+        bf16x8 af[8], wf[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(st + b_off + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) af[mt] = *(const bf16x8*)(st + a_off + mt * 1024);
+        LDS_WAIT();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    ColVals cv[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) cv[nt] = load_cols<MODE>(epi, n0 + wave * 64 + nt * 16 + 4 * g, N);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + mt * 16 + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            epilogue4<MODE>(epi, m, n0 + wave * 64 + nt * 16 + 4 * g, cv[nt], acc[mt][nt]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -501,8 +609,8 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
 // host launchers
 // ------------------------------------------------------------------------------------------
 static bool g_attr_done = false;
-static bool g_use_256 = true;
-void uvit_gemm_set_variant(int use_256) { g_use_256 = use_256 != 0; }
+static int g_variant = 3;
+void uvit_gemm_set_variant(int v) { g_variant = v; }
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
@@ -514,6 +622,9 @@ static void gemm_init_once() {
 #define ALLOW256(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES)
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU);
 #undef ALLOW256
+#define ALLOW2(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)
+    ALLOW2(EPI_BF16); ALLOW2(EPI_QKV); ALLOW2(EPI_GELU); ALLOW2(EPI_RESID); ALLOW2(EPI_F32); ALLOW2(EPI_PATCH); ALLOW2(EPI_DGELU);
+#undef ALLOW2
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     g_attr_done = true;
 }
@@ -523,11 +634,20 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
-    const bool big = g_use_256 && (N % T_BN) == 0 && M >= 1024 && K >= 2 * BK;
-    const int grid = big ? ((M + T_BM - 1) / T_BM) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // variant: 0 = 128x128 (any shape), 1 = 256x256 one workgroup/CU, 2 = 128x256 two workgroups/CU,
+    // 3 = auto, from tools/bench_gemm.py on MI355X at M = 25216 (profiles/round1_gemm_variants.txt):
+    //   N <= 1024 (proj, fc2, every dgrad): 128x128, 1182 tiles keep both resident workgroups of all CUs busy;
+    //   N >= 3072 (fc1, its GELU' dgrad):   256x256, fewest operand bytes per FLOP beside a heavy epilogue;
+    //   between (qkv):                      128x256.
+    const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0;
+    int variant = shape_ok ? g_variant : 0;
+    if (variant == 3) variant = N <= 1024 ? 0 : (N >= 3072 ? 1 : 2);
+    const int grid = variant == 1 ? ((M + T_BM - 1) / T_BM) * (N / T_BN)
+                   : variant == 2 ? ((M + P_BM - 1) / P_BM) * (N / P_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
-#define L(MODE) do { if (big) hipLaunchKernelGGL(gemm_nt256_kernel<MODE>, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+#define L(MODE) do { if (variant == 1) hipLaunchKernelGGL(gemm_nt256_kernel<MODE>, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+        else if (variant == 2) hipLaunchKernelGGL(gemm_nt2_kernel<MODE>, dim3(grid), dim3(P_THREADS), P_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi); } while (0)
     switch (mode) {
         case EPI_BF16: L(EPI_BF16); break;
