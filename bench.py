@@ -103,6 +103,10 @@ def main():
     x, mask = synthetic_batch(a.batch, 1000 + rank, dev)
     mask = mask.reshape(a.batch, -1).contiguous()
     L = lib()
+    if os.environ.get("UVIT_TN_TARGET"):
+        L.uvit_set_tn_split_target(int(os.environ["UVIT_TN_TARGET"]))     # tuning experiments only
+    if os.environ.get("UVIT_GEMM_VARIANT"):
+        L.uvit_set_gemm_variant(int(os.environ["UVIT_GEMM_VARIANT"]))
 
     def step(i):
         hp = make_step_params(list(range(6, 12)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, 0, i)
@@ -164,7 +168,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "step_mfma_frac": round(value / world * GFLOP_PER_IMAGE * 1e9 / PEAK_BF16, 4),
                        "final_loss": round(float(stats[0]), 5)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": TRAFFIC_BYTES,
                          "algorithmic_bytes": ALGO_BYTES, "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4),

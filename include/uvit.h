@@ -134,6 +134,8 @@ int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, co
 /* Tuning / test hook for large NT GEMM shapes: 3 = auto by N (default), 2 = 128x256 tile with two workgroups
  * per CU, 1 = 256x256 with one workgroup per CU, 0 = 128x128 generic kernel. Process-wide. */
 int uvit_set_gemm_variant(int v);
+/* Tuning hook: number of workgroups the wgrad GEMM's token split aims for (default 512). Process-wide. */
+int uvit_set_tn_split_target(int wgs);
 /* dual = 1 (default): teacher forward and the wgrad GEMMs run on an internal second HIP stream beside the
  * caller's stream; dual = 0: everything on the caller's stream (used to time one kernel in isolation).
  * Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */

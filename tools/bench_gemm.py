@@ -62,11 +62,6 @@ def time_tn(M, N, K, iters=20):
 if __name__ == "__main__":
     M = 25216
     names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu"}
-    print("== NT: K sweep (mode bf16) ==")
-    for N in (3072, 768):
-        for K in (128, 256, 768, 1536, 3072, 6144):
-            us, tf = time_nt(0, M, N, K)
-            print(f"N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
     print("== NT: step shapes, variants 0 (128x128) / 1 (256x256) / 2 (128x256 x2 per CU) ==")
     for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
         row = []
@@ -76,11 +71,18 @@ if __name__ == "__main__":
             row.append(f"v{v}: {us:7.1f} us {tf:6.1f} TF/s")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
     L.uvit_set_gemm_variant(3)
-    print("== NT: square references ==")
+    print("== NT: square references (variant 1) ==")
+    L.uvit_set_gemm_variant(1)
     for n in (4096, 8192):
         us, tf = time_nt(0, n, n, n, iters=5)
         print(f"{n}^3: {us:8.1f} us  {tf:7.1f} TF/s")
-    print("== TN (wgrad) ==")
+    L.uvit_set_gemm_variant(3)
+    print("== TN (wgrad), split target sweep ==")
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
-        us, tf = time_tn(M, N, K)
-        print(f"wgrad N={N:5d} K={K:5d}: {us:8.1f} us  {tf:7.1f} TF/s")
+        row = []
+        for tgt in (256, 384, 512, 768, 1024, 1536):
+            L.uvit_set_tn_split_target(tgt)
+            us, tf = time_tn(M, N, K)
+            row.append(f"{tgt}: {us:6.1f}us {tf:5.0f}TF")
+        print(f"wgrad N={N:5d} K={K:5d}: " + " | ".join(row))
+    L.uvit_set_tn_split_target(512)

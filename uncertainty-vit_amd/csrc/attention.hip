@@ -207,7 +207,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
 // backward, query-owned: dQ, delta, and the rel-pos-bias gradient summed over a batch chunk
 // ------------------------------------------------------------------------------------------
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(BWD_WAVES * 64)
+__global__ __launch_bounds__(BWD_WAVES * 64, 4)      // two workgroups per CU: 384 workgroups fit one round
 void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                         const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
                         bf16* __restrict__ dqkv, float* __restrict__ dbias_slab, int accumulate_slab,

@@ -298,6 +298,8 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
 
 extern "C" int uvit_set_gemm_variant(int v) { if (v < 0 || v > 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
 
+extern "C" int uvit_set_tn_split_target(int wgs) { uvit_gemm_set_tn_target(wgs); return UVIT_OK; }
+
 extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
     if (!e) return UVIT_ERR_ARG;
     e->dual = dual != 0;

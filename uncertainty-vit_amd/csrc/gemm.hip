@@ -610,6 +610,8 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
 // ------------------------------------------------------------------------------------------
 static bool g_attr_done = false;
 static int g_variant = 3;
+static int g_tn_target = 512;     // MI355X sweep (tools/bench_gemm.py): 512 beats 256..1536 on all four wgrad shapes
+void uvit_gemm_set_tn_target(int wgs) { g_tn_target = wgs > 0 ? wgs : 512; }
 void uvit_gemm_set_variant(int v) { g_variant = v; }
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
@@ -672,7 +674,7 @@ int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int
     // split the token reduction until ~1024 workgroups are in flight (2 resident per CU x 256 CUs, two rounds)
     int split = 1;
     if (allow_split) {
-        split = 1024 / tiles;
+        split = g_tn_target / tiles;
         if (split > nm / 8) split = nm / 8;
         if (split < 1) split = 1;
     }

@@ -80,6 +80,7 @@ _PROTOTYPES = {
     "uvit_train_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_engine_read_stats": (_i, [_vp, _vp, _vp]),
     "uvit_set_gemm_variant": (_i, [_i]),
+    "uvit_set_tn_split_target": (_i, [_i]),
     "uvit_engine_set_streams": (_i, [_vp, _i]),
     "uvit_engine_profile": (_i, [_vp, _i, _i]),
     "uvit_engine_profile_read": (_i, [_vp, _vp, _vp, _vp]),
