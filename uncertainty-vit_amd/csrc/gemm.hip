@@ -403,23 +403,24 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int
     // loader: a wave-instruction covers 16 rows x 64 B.  A = 8 instructions (2 per wave), W = 16 (4 per wave)
     const int srow = lane >> 2;
     const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);          // row>>2 & 3 == lane>>4 (instruction rows start at a multiple of 16)
-    const bf16* a_src[2];
-    const bf16* w_src[4];
+    // 32-bit element offsets from the (scalar) base pointers keep the loader at 6 VGPRs
+    uint32_t a_src[2], w_src[4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         int r = m0 + (j * 4 + wave) * 16 + srow; r = r < M ? r : M - 1;
-        a_src[j] = A + (size_t)r * lda + schunk * 8;
+        a_src[j] = (uint32_t)r * (uint32_t)lda + schunk * 8;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w_src[j] = W + (size_t)(n0 + (j * 4 + wave) * 16 + srow) * ldw + schunk * 8;
+    for (int j = 0; j < 4; ++j) w_src[j] = (uint32_t)(n0 + (j * 4 + wave) * 16 + srow) * (uint32_t)ldw + schunk * 8;
     const int nk = K / P_BK;
     auto issue = [&](int t) {
         if (t < nk) {
             char* st = smem + (t % 3) * P_STAGE;
+            const uint32_t k0 = (uint32_t)t * P_BK;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(a_src[j] + (size_t)t * P_BK, st + (j * 4 + wave) * 1024);
+            for (int j = 0; j < 2; ++j) glds16(A + (a_src[j] + k0), st + (j * 4 + wave) * 1024);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(w_src[j] + (size_t)t * P_BK, st + P_STAGE_A + (j * 4 + wave) * 1024);
+            for (int j = 0; j < 4; ++j) glds16(W + (w_src[j] + k0), st + P_STAGE_A + (j * 4 + wave) * 1024);
         }
     };
 
@@ -434,27 +435,45 @@ void gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline: fragments of K-tile t+1 are read from LDS (into the other register set) while the MFMAs
+    // of K-tile t run; the global loads of K-tile t+3 go into the stage whose fragments were consumed an iteration
+    // ago.  One barrier per K-tile: it publishes "K-tile t+2 has landed" and "stage (t+1)%3 has been read".
+    bf16x8 afA[8], wfA[4], afB[8], wfB[4];
+#define LOADF(af_, wf_, t_) do { const char* st_ = smem + ((t_) % 3) * P_STAGE; \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) wf_[nt] = *(const bf16x8*)(st_ + b_off + nt * 1024); \
+        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) af_[mt] = *(const bf16x8*)(st_ + a_off + mt * 1024); } while (0)
+#define MMA32(af_, wf_) do { __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_[nt], af_[mt], acc[mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0); } while (0)
+#define STEP(afc, wfc, afn, wfn, t_) do { \
+        issue((t_) + 3);                                            /* stage t%3: consumed last iteration */ \
+        if ((t_) + 1 < nk) LOADF(afn, wfn, (t_) + 1);               /* K-tile t+1: published by the last barrier */ \
+        MMA32(afc, wfc); \
+        if ((t_) + 3 < nk) VM_WAIT(6); else VM_WAIT(0);             /* K-tile t+2 landed (t+3's 6 loads may fly) */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this wave is done reading stage (t+1)%3 */ \
+        RAW_BARRIER(); } while (0)
+
     issue(0);
     issue(1);
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) VM_WAIT(6); else VM_WAIT(0);        // K-tile t landed (tile t+1's 6 loads may still fly)
-        RAW_BARRIER();                                       // ... for every wave; stage (t+2)%3 is no longer read
-        issue(t + 2);
-        const char* st = smem + (t % 3) * P_STAGE;
-        bf16x8 af[8], wf[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(st + b_off + nt * 1024);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) af[mt] = *(const bf16x8*)(st + a_off + mt * 1024);
-        LDS_WAIT();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+    issue(2);
+    if (nk >= 3) VM_WAIT(12); else if (nk == 2) VM_WAIT(6); else VM_WAIT(0);    // K-tile 0 landed
+    RAW_BARRIER();
+    LOADF(afA, wfA, 0);
+    if (nk >= 3) VM_WAIT(6); else VM_WAIT(0);                                    // K-tile 1 landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RAW_BARRIER();
+    // invariant at the top of STEP(t): fragments of t in registers, K-tile t+1 published, t+2 in flight, stage t%3 free
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        STEP(afA, wfA, afB, wfB, t);
+        STEP(afB, wfB, afA, wfA, t + 1);
     }
+    if (t < nk) STEP(afA, wfA, afB, wfB, t);
+#undef LOADF
+#undef MMA32
+#undef STEP
 
     ColVals cv[4];
 #pragma unroll
