@@ -1,0 +1,38 @@
+"""Worker for tests/test_gpu_ddp.py: one data-parallel rank of the native step (gloo rendezvous, GPU tensors)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    out = os.environ["UVIT_OUT"]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+    from oracle import vit_oracle as vo
+    from oracle.closed_form import closed_form_images, exact_masks
+    from gpu_util import native_model, native_steps, native_trainer
+    cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=3, num_heads=2, init_values=0.1)
+    B = 8
+    x = closed_form_images("ddp", B, 48)
+    mask = exact_masks(B, 9, 4, 77)
+    per = B // world
+    xs, ms = x[rank * per:(rank + 1) * per].cuda(), mask[rank * per:(rank + 1) * per].cuda()
+    model, _ = native_model(cfg)
+    ema, opt = native_trainer(model)
+    stats = native_steps(model, ema, opt, [(xs, ms)] * 2, [1, 2])
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()},
+                "ema": {k: v.cpu() for k, v in ema.module.state_dict().items()},
+                "loss": [s["loss"] for s in stats], "gnorm": [s["grad_norm"] for s in stats]}, f"{out}.rank{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
