@@ -22,5 +22,7 @@ def run_smoke():
     assert abs(st["loss"] - ref.loss) < 5e-3 * abs(ref.loss) + 1e-4, (st["loss"], ref.loss)
     assert abs(st["grad_norm"] - ref.grad_norm) < 3e-2 * ref.grad_norm, (st["grad_norm"], ref.grad_norm)
     w = model.state_dict()["blocks.1.mlp.fc1.weight"].cpu()
-    torch.testing.assert_close(w, p["blocks.1.mlp.fc1.weight"], rtol=0, atol=2.5e-3)   # one AdamW step moves by <= lr
+    # the first AdamW step moves every weight by +-lr (2e-3); bf16 noise may flip the sign of a ~0 gradient
+    diff = (w - p["blocks.1.mlp.fc1.weight"]).abs()
+    assert diff.max() <= 2 * 2e-3 + 1e-4 and (diff > 5e-4).float().mean() < 0.02, (diff.max(), (diff > 5e-4).float().mean())
     print(f"smoke ok: loss {st['loss']:.5f} (oracle {ref.loss:.5f}), grad_norm {st['grad_norm']:.4f} (oracle {ref.grad_norm:.4f})")
