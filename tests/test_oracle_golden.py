@@ -127,3 +127,41 @@ def test_adamw_matches_torch_optim():
         vo.adamw_step(p, g, m, v, s + 1, hp)
     for k in p:
         torch.testing.assert_close(p[k], ref[k].detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_two_stream_model_and_step(golden_dir):
+    """Two-stream ("--stochastic") model: forward, Wasserstein loss, gradients, dead cov_qkv.weight, EMA."""
+    from oracle import vit_oracle_dist as vd
+    fx = np.load(os.path.join(golden_dir, "dist_d48.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=float(fx["init_values"]))
+    assert list(vd.param_shapes(cfg)) == fx["names"].tolist()           # reference state-dict order
+    p = closed_form_state(vd.param_shapes(cfg), gamma=cfg.init_values)
+    x = closed_form_images("d48/0", B, img)
+    mask = torch.from_numpy(fx["mask0"])
+    em, ec = vd.forward(p, cfg, x, None, True, "end")
+    for i in range(depth):
+        check_entry(fx, f"fwd/mean_end{i}", em[i], RT, AT)
+        check_entry(fx, f"fwd/cov_end{i}", ec[i], RT, AT)
+    sm, sc = vd.forward(p, cfg, x, mask, False)
+    check_entry(fx, "fwd/student_mean", sm, RT, AT)
+    check_entry(fx, "fwd/student_cov", sc, RT, AT)
+    hp = vo.StepHParams(target_layers=tuple(int(v) for v in fx["target_layers"]))
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    for s in range(steps):
+        xs = closed_form_images(f"d48/{s}", B, img)
+        res, lw, _, _ = vd.train_step(p, ema, m, v, cfg, hp, xs, torch.from_numpy(fx[f"mask{s}"]), s + 1, lam=1e-2)
+        assert res.loss == pytest.approx(float(fx["step/loss"][s]), rel=2e-4)
+        assert res.grad_norm == pytest.approx(float(fx["step/grad_norm"][s]), rel=2e-3)
+        assert lw > 0
+        if s == 0:
+            assert set(fx["grad0_none"].tolist()) == {f"blocks.{i}.attn.cov_qkv.weight" for i in range(depth)}
+            assert set(entries(fx, "grad0")) == set(res.grads)
+            for n in entries(fx, "grad0"):
+                check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
+    for n in entries(fx, "post"):
+        check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)
+    for n in entries(fx, "ema"):
+        check_entry(fx, "ema/" + n, ema[n], 1e-5, 1e-7)

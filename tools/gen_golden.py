@@ -121,6 +121,64 @@ def gen_model_case(mc, eng, tag, img, dim, depth, heads, init_values, B, n_mask,
 CURVE_LR = 1e-4   # constant; the README recipe warms up from 1e-6, 2e-3 from step 0 is chaotic on a tiny model
 
 
+def gen_dist_case(mc, eng, tag, img, dim, depth, heads, init_values, B, n_mask, seed, steps=2):
+    """Two-stream model (DistVisionTransformerForCyclicalTraining) + train_one_epoch(stochastic=True)."""
+    import modeling_cyclical_dist as mcd
+    from oracle.closed_form import closed_form
+    model = mcd.DistVisionTransformerForCyclicalTraining(
+        img_size=img, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=init_values, use_shared_rel_pos_bias=True,
+        use_abs_pos_emb=False, drop_path_rate=0.0, attn_drop_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype == torch.float32}
+    model.load_state_dict(closed_form_state(shapes, gamma=init_values), strict=False)
+    n_patches = (img // 16) ** 2
+    batches = [(closed_form_images(f"{tag}/{s}", B, img), exact_masks(B, n_patches, n_mask, seed + s)) for s in range(steps)]
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, steps], dtype=np.int64),
+           "init_values": np.float64(init_values), "names": np.array(list(shapes.keys()))}
+    x, mask = batches[0]
+    model.eval()
+    with torch.no_grad():
+        em, ec = model(x, None, True, layer_results="end")
+        sm, sc = model(x, mask, return_all_tokens=False)
+    for i in range(depth):
+        put(out, f"fwd/mean_end{i}", em[i])
+        put(out, f"fwd/cov_end{i}", ec[i])
+    put(out, "fwd/student_mean", sm)
+    put(out, "fwd/student_cov", sc)
+    for s, (_, bm) in enumerate(batches):
+        out[f"mask{s}"] = bm.numpy()
+    model.train()
+    import optim_factory
+    import timm.utils as U
+    ema = U.ModelEmaV2(model, decay=0.9998)
+    args = SimpleNamespace(opt="adamw", lr=2e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+    opt = optim_factory.create_optimizer(args, model)
+    scaler = ref_harness.HarnessScaler()
+    tl = list(range(depth // 2, depth))
+    losses, gnorms = [], []
+    for s, (bx, bm) in enumerate(batches):
+        st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, tl, [((bx, bm), torch.zeros(1))], opt, torch.device("cpu"), 0, scaler,
+                                 max_norm=3.0, l1_beta=2.0, start_steps=s, layer_results="end", loss_scale=-1,
+                                 target_layer_norm_last=True, post_target_layer_norm=True, stochastic=True, lambda_pretraining=1e-2)
+        losses.append(st["loss"]); gnorms.append(float(st["grad_norm"]))
+        if s == 0:
+            pn = [n for n, _ in model.named_parameters()]
+            out["grad0_none"] = np.array([n for n, g in zip(pn, scaler.grads) if g is None])
+            for n, g in zip(pn, scaler.grads):
+                if g is not None:
+                    put(out, "grad0/" + n, g)
+    out["target_layers"] = np.array(tl, dtype=np.int64)
+    out["step/loss"], out["step/grad_norm"] = np.array(losses), np.array(gnorms)
+    for k, v in model.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "post/" + k, v)
+    for k, v in ema.module.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "ema/" + k, v)
+    np.savez_compressed(os.path.join(OUT, f"dist_{tag}.npz"), **out)
+    print("wrote dist", tag, "loss", losses, "gnorm", gnorms)
+
+
 def gen_loss_curve(mc, eng):
     img, dim, depth, heads, B, n_mask = 48, 128, 2, 2, 4, 5
     model = build(mc, img, dim, depth, heads, 0.1)
@@ -206,6 +264,8 @@ def main():
     if a.only in (None, "model"):
         gen_model_case(mc, eng, "t48", img=48, dim=128, depth=2, heads=2, init_values=0.1, B=3, n_mask=4, seed=1)
         gen_model_case(mc, eng, "t32", img=32, dim=192, depth=3, heads=3, init_values=1e-4, B=2, n_mask=2, seed=2)
+    if a.only in (None, "dist"):
+        gen_dist_case(mc, eng, "d48", img=48, dim=128, depth=2, heads=2, init_values=0.1, B=3, n_mask=4, seed=41)
     if a.only in (None, "curve"):
         gen_loss_curve(mc, eng)
     if a.only in (None, "vitb"):
