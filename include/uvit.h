@@ -36,6 +36,7 @@ typedef struct uvit_config {
     float attn_drop_rate;             /* --attn_drop_rate */
     float drop_path_rate;             /* --drop_path; per-layer linspace(0, rate, depth) */
     int32_t bias_chunk;               /* batch elements summed in registers per rel-pos-bias slab (0 = default 8) */
+    int32_t two_stream;               /* 1: DistVisionTransformerForCyclicalTraining (mean, cov) model, modeling_cyclical_dist.py:14-165 */
 } uvit_config;
 
 /* One tensor of the flat parameter arena; `name` is the reference state-dict key. */
@@ -44,7 +45,7 @@ typedef struct uvit_layout_entry {
     int64_t offset;   /* in floats, multiple of 64 */
     int64_t numel;
     int32_t ndim;
-    int32_t decay;    /* 1 = weight-decay group (optim_factory.py:58-97) */
+    int32_t decay;    /* 1 = weight-decay group (optim_factory.py:58-97); 2 = never receives a gradient in the reference (kept constant) */
     int64_t shape[4];
 } uvit_layout_entry;
 
@@ -82,6 +83,7 @@ typedef struct uvit_step_params {
     uint32_t seed;                    /* dropout / drop-path stream */
     uint32_t it;                      /* global iteration, decorrelates masks between steps */
     int32_t train_dropout;            /* 1: apply attn_drop_rate and drop_path_rate in the student */
+    float lambda_pretraining;         /* WassersteinLoss weight (two-stream model only; --lambda_pretraining) */
 } uvit_step_params;
 
 int uvit_version(void);
@@ -108,11 +110,13 @@ int uvit_engine_forward_features(uvit_engine* e, int which, const float* images,
                                  int train_dropout, uint32_t seed, uint32_t it, uvit_stream stream);
 /* norm + drop cls + (masked-row gather) + lm_head (modeling_cyclical.py:207,215-225) on the last
  * forward_features result.  all_tokens=1: out (B*P, C); else out (count, C) rows in mask order.
- * out must hold B*P*C floats; *count_dev (device int) receives the number of valid rows. */
+ * out must hold B*P*C floats; *count_dev (device int) receives the number of valid rows.
+ * which: bit 0 = teacher weights, bit 1 = covariance stream (two-stream model: cov_lm_head). */
 int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float* out, int32_t* count_dev, uvit_stream stream);
 
 /* Device pointers into the workspace after a forward: name in {"x" (layer 0..depth residual stream
- * (B,N,C) f32), "xm" (after the attention branch), "loss", "grad_norm", "targets", "outputs", "count"}. */
+ * (B,N,C) f32), "xm" (after the attention branch), "loss", "grad_norm", "targets", "outputs", "count"};
+ * two-stream model: also "x_cov", "xm_cov", "targets_cov", "outputs_cov". */
 void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer);
 
 /* ---- the training step, engine_for_cyclical.py:58-186 ---- */
@@ -164,12 +168,22 @@ int uvit_op_gemm_nt(int mode, const void* A_bf16, const void* W_bf16, int M, int
 /* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64 */
 int uvit_op_gemm_tn(const void* Y_bf16, const void* X_bf16, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
                     uvit_stream stream);
-/* Attention core, modeling_finetune.py:152-185. qkv (B,N,3,H,64) bf16; biasP (H,NP,NP) f32 or NULL */
+/* Attention core, modeling_finetune.py:152-185. qkv (B,N,3,H,64) bf16; biasP (H,NP,NP) f32 or NULL in the kernels'
+ * private layout built by uvit_op_relpos_gather: bias * log2(e), -1e30 in padded key columns; lse is in log2 units */
 int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
                      float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
 int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                      float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H, int N,
                      int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
+/* Two-stream Wasserstein attention core (modeling_finetune_dist.py:129-162 + uncertainty_evaluations.py:276-294).
+ * qkv_m: mean-stream (B,N,3,H,64) bf16; qkv_c: covariance stream, already ELU(.)+1.  The backward returns the
+ * gradient of the PRE-ELU covariance QKV (ELU' folded in).  biasP / lse units as for uvit_op_attn_fwd. */
+int uvit_op_attn2_fwd(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse, int B, int H,
+                      int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
+int uvit_op_attn2_bwd(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
+                      const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* dbias_slab,
+                      int accumulate_slab, int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
+                      uint32_t layer, uvit_stream stream);
 int uvit_op_relpos_gather(const float* table, const int32_t* index, float* biasP, int H, int N, int NP, uvit_stream stream);
 int uvit_op_relpos_scatter(const float* slab, int nslab, const int32_t* index, float* dtable, int H, int N, int NP,
                            uvit_stream stream);

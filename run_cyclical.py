@@ -145,8 +145,14 @@ class SyntheticPretrainSet(torch.utils.data.Dataset):
 
 
 def get_model(args):
-    print(f"Creating model: {args.model}")
-    return create_model(args.model, pretrained=False, drop_path_rate=args.drop_path, drop_rate=args.drop,
+    name = args.model
+    if args.stochastic and name == "beit_base_patch16_224":
+        # README.md:42-61 documents `--model beit_base_patch16_224 --stochastic`, which cannot run in the reference
+        # (the base model returns no (mean, cov) pairs).  The only self-consistent reading is the
+        # two-stream architecture registered as dist_beit_base_patch16_224 (modeling_cyclical.py:304-323).
+        name = "dist_beit_base_patch16_224"
+    print(f"Creating model: {name}")
+    return create_model(name, pretrained=False, drop_path_rate=args.drop_path, drop_rate=args.drop,
                         use_shared_rel_pos_bias=args.rel_pos_bias, use_abs_pos_emb=args.abs_pos_emb,
                         init_values=args.layer_scale_init_value, attn_drop_rate=args.attn_drop_rate,
                         gp_layer=args.gp_layer, gumbel_softmax=args.gumbel_softmax, sinkformer=args.sinkformer,
@@ -170,8 +176,6 @@ def main(args):
         raise NotImplementedError("--seed_model (checkpoint surgery with rel-pos interpolation) is out of scope")
     if args.data_set != "SYNTHETIC":
         raise NotImplementedError("only --data_set SYNTHETIC is available here: the image pipelines of datasets.py are out of scope")
-    if args.stochastic:
-        raise NotImplementedError("--stochastic (two-stream dist_beit_base_patch16_224) is not built yet (DESIGN.md, next)")
 
     dataset_train = SyntheticPretrainSet(args.synthetic_len, args.input_size, args.window_size, args.num_mask_patches, args.seed)
     num_tasks, global_rank = utils.get_world_size(), utils.get_rank()

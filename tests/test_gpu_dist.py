@@ -1,0 +1,156 @@
+"""GPU parity of the two-stream ("--stochastic") path: Wasserstein attention operator, model forward and
+training steps against reference-generated goldens (tests/golden/dist_d48.npz)."""
+import ctypes as C
+import os
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import check_entry, entries
+from oracle import vit_oracle as vo
+from oracle import vit_oracle_dist as vd
+from oracle.closed_form import closed_form_images, closed_form_state
+
+pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
+
+
+def P(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).cuda()
+
+
+def close(a, b, rtol, atol, what):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    bad = (err > atol + rtol * b.abs()).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} off, max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 2, 10), (2, 12, 197), (3, 2, 37)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_wasserstein_attention_fwd_bwd(B, H, N, p_drop):
+    from uncertainty_vit_amd import native
+    from oracle.vit_oracle import attn_keep_mask
+    L = native.lib()
+    Cd = H * 64
+    qkv_m = rnd(B * N, 3 * Cd, seed=1).to(torch.bfloat16)
+    pre_c = rnd(B * N, 3 * Cd, seed=2).to(torch.bfloat16)                  # pre-ELU covariance QKV
+    qkv_c = (F.elu(pre_c.float()) + 1).to(torch.bfloat16)                   # what the QKV epilogue stores
+    bias = rnd(H, N, N, scale=0.5, seed=3)
+    biasP = torch.zeros(H, 208, 208, device="cuda"); biasP[:, :, N:] = -1e30; biasP[:, :N, :N] = bias * LOG2E
+    seed, layer = 77, 1
+    keep = attn_keep_mask(seed, layer, B, H, N, p_drop).cuda() if p_drop > 0 else None
+    out_m = torch.zeros(B * N, Cd, dtype=torch.bfloat16, device="cuda"); out_c = torch.zeros_like(out_m)
+    lse = torch.zeros(B, H, N, device="cuda")
+    assert L.uvit_op_attn2_fwd(P(qkv_m), P(qkv_c), P(biasP), P(out_m), P(out_c), P(lse), B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
+
+    def ref(qm, qc_val):
+        q, k, v = qm.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        cq, ck, cv = qc_val.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        a = torch.sigmoid(-vd.wasserstein_distance_matmul(q * 0.125, cq, k, ck) + 1e-24)
+        a = (a + bias).softmax(-1)
+        if keep is not None:
+            a = a * keep
+        return (a @ v).transpose(1, 2).reshape(B, N, Cd), ((a ** 2) @ cv).transpose(1, 2).reshape(B, N, Cd)
+
+    qm = qkv_m.float().requires_grad_(True)
+    pc = pre_c.float().requires_grad_(True)
+    # the kernel sees the bf16-rounded ELU+1 values; differentiate through ELU at the same point
+    qc_val = qkv_c.float() + (F.elu(pc) + 1 - (F.elu(pc) + 1).detach())
+    rm, rc = ref(qm, qc_val)
+    close(out_m.view(B, N, Cd), rm, 2e-2, 1e-2, "mean out")
+    close(out_c.view(B, N, Cd), rc, 3e-2, 1e-2 * rc.abs().max().item() + 1e-3, "cov out")
+    d_m = rnd(B * N, Cd, scale=0.5, seed=4).to(torch.bfloat16); d_c = rnd(B * N, Cd, scale=0.5, seed=5).to(torch.bfloat16)
+    bq = bias.clone().requires_grad_(True)
+    bias_saved = bias
+    bias = bq
+    rm, rc = ref(qm, qc_val)
+    (rm * d_m.float().view(B, N, Cd)).sum().add((rc * d_c.float().view(B, N, Cd)).sum()).backward()
+    bias = bias_saved
+    delta = torch.zeros(B, H, N, device="cuda")
+    dq_m = torch.zeros_like(qkv_m); dq_c = torch.zeros_like(qkv_m)
+    chunk = 2
+    slab = torch.zeros((B + chunk - 1) // chunk, H, 208, 208, device="cuda")
+    assert L.uvit_op_attn2_bwd(P(qkv_m), P(qkv_c), P(out_m), P(out_c), P(d_m), P(d_c), P(biasP), P(lse), P(delta), P(dq_m), P(dq_c),
+                               P(slab), 0, chunk, B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
+    close(dq_m, qm.grad, 5e-2, 2e-2 * qm.grad.abs().max().item(), "d qkv (mean stream)")
+    close(dq_c, pc.grad, 5e-2, 2e-2 * pc.grad.abs().max().item(), "d qkv (cov stream, pre-ELU)")
+    close(slab.sum(0)[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
+
+
+def dist_model(cfg):
+    from uncertainty_vit_amd.modeling_cyclical import DistVisionTransformerForCyclicalTraining
+    m = DistVisionTransformerForCyclicalTraining(
+        img_size=cfg.img_size, patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4,
+        qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=cfg.init_values,
+        use_shared_rel_pos_bias=True, use_abs_pos_emb=False)
+    sd = closed_form_state(vd.param_shapes(cfg), gamma=cfg.init_values)
+    m.load_state_dict(sd, strict=False)
+    return m.cuda(), sd
+
+
+def load(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "dist_d48.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    return fx, vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=float(fx["init_values"])), B, steps
+
+
+def test_two_stream_forward_vs_golden(golden_dir):
+    fx, cfg, B, _ = load(golden_dir)
+    model, _ = dist_model(cfg)
+    model.eval()
+    x = closed_form_images("d48/0", B, cfg.img_size).cuda()
+    em, ec = model(x, None, True, layer_results="end")
+    for i in range(cfg.depth):
+        check_entry(fx, f"fwd/mean_end{i}", em[i], 2e-2, 2e-2)
+        check_entry(fx, f"fwd/cov_end{i}", ec[i], 2e-2, 2e-2)
+    sm, sc = model(x, torch.from_numpy(fx["mask0"]).cuda(), return_all_tokens=False)
+    check_entry(fx, "fwd/student_mean", sm, 2e-2, 2e-2)
+    check_entry(fx, "fwd/student_cov", sc, 2e-2, 2e-2)
+
+
+def test_two_stream_train_steps_vs_golden(golden_dir):
+    from uncertainty_vit_amd import engine_for_cyclical as eng, optim_factory, utils
+    fx, cfg, B, steps = load(golden_dir)
+    model, sd0 = dist_model(cfg)
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
+    ema = utils.ModelEmaV2(model, decay=0.9998)
+    opt = optim_factory.create_optimizer(A(), model)
+    tl = [int(v) for v in fx["target_layers"]]
+    stats = []
+    for s in range(steps):
+        x = closed_form_images(f"d48/{s}", B, cfg.img_size).cuda()
+        loader = [((x, torch.from_numpy(fx[f"mask{s}"]).cuda()), torch.zeros(1))]
+        stats.append(eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, tl, loader, opt, torch.device("cuda"), 0,
+                                         utils.NativeScalerWithGradNormCount(), max_norm=3.0, l1_beta=2.0, start_steps=s,
+                                         layer_results="end", loss_scale=-1, target_layer_norm_last=True, post_target_layer_norm=True,
+                                         stochastic=True, lambda_pretraining=1e-2))
+        if s == 0:
+            grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    assert stats[0]["loss"] == pytest.approx(float(fx["step/loss"][0]), rel=5e-3)
+    assert stats[0]["grad_norm"] == pytest.approx(float(fx["step/grad_norm"][0]), rel=3e-2)
+    assert stats[1]["loss"] == pytest.approx(float(fx["step/loss"][1]), rel=2e-2)
+    gmax = max(float(np.abs(fx[k]).max()) for k in fx.files if k.startswith("grad0/") and not k.endswith("/sum"))
+    for n in entries(fx, "grad0"):
+        check_entry(fx, "grad0/" + n, grads[n], 5e-2, 2e-2 * gmax, what="[dist] ")
+    for n in fx["grad0_none"].tolist():          # dead cov_qkv.weight: no gradient, never stepped (not even weight decay)
+        assert grads[n].abs().sum() == 0
+        assert torch.equal(model.state_dict()[n].cpu(), sd0[n])
+    sd, esd = model.state_dict(), ema.module.state_dict()
+    for n in entries(fx, "post"):
+        check_entry(fx, "post/" + n, sd[n], 0, steps * 2 * 2e-3 + 1e-4, what="post ")
+    for n in entries(fx, "ema"):
+        check_entry(fx, "ema/" + n, esd[n], 0, steps * 2 * 2e-3 * 2e-4 + 1e-5, what="ema ")

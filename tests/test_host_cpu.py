@@ -58,7 +58,7 @@ def test_arena_layout_matches_reference_state_dict(native):
         name, shape = e.name.decode(), tuple(e.shape[: e.ndim])
         seen[name] = shape
         assert e.offset % 64 == 0 and e.numel == int(np.prod(shape))
-        assert (e.offset < nd.value) == bool(e.decay)
+        assert (e.offset < nd.value) == (e.decay == 1)
         spans.append((e.offset, e.offset + e.numel))
         end = max(end, e.offset + e.numel)
     assert seen == ref                                        # 189 float tensors, reference names and shapes

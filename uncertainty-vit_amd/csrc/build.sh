@@ -6,7 +6,7 @@ OUT=${1:-../libuvit.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wall -Wno-unused-function"
 mkdir -p obj
 pids=()
-for f in gemm attention norm elementwise optim engine; do
+for f in gemm attention attention2 norm elementwise optim engine; do
   ( hipcc $FLAGS -c $f.hip -o obj/$f.o ) &
   pids+=($!)
 done

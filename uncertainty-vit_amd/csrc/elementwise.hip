@@ -289,16 +289,16 @@ void transpose_batch_kernel(const TransposeDesc* __restrict__ descs, int ndesc) 
     }
 }
 
-// scales[(layer*2 + branch)*B + b] : 1/keep or 0 (timm drop_path, modeling_finetune.py:51-62); rate 0 -> 1
-__global__ void droppath_kernel(float* __restrict__ scales, const float* __restrict__ rates, int depth, int B,
+// scales[(layer*nbr + branch)*B + b] (nbr = 2 draws per block, 4 for the two-stream model) : 1/keep or 0 (timm drop_path, modeling_finetune.py:51-62); rate 0 -> 1
+__global__ void droppath_kernel(float* __restrict__ scales, const float* __restrict__ rates, int depth, int nbr, int B,
                                 uint32_t seed, uint32_t step) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= depth * 2 * B) return;
-    const int b = i % B, lb = i / B, layer = lb >> 1, br = lb & 1;
+    if (i >= depth * nbr * B) return;
+    const int b = i % B, lb = i / B, layer = lb / nbr, br = lb - layer * nbr;
     const float r = rates[layer];
     float v = 1.0f;
     if (r > 0.f) {
-        const uint32_t key = uvit_hash32(seed ^ ((step * 2u * depth + 2u * layer + br + 1u) * 0x9E3779B9u));
+        const uint32_t key = uvit_hash32(seed ^ ((step * (uint32_t)nbr * depth + (uint32_t)nbr * layer + br + 1u) * 0x9E3779B9u));
         v = uvit_hash32((uint32_t)b ^ key) >= uvit_drop_threshold(r) ? 1.0f / (1.0f - r) : 0.f;
     }
     scales[i] = v;
@@ -374,7 +374,91 @@ int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int total_tile
     hipLaunchKernelGGL(transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, s, (const TransposeDesc*)descs_dev, ndesc);
     return uvit_check_launch();
 }
-int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step, hipStream_t s) {
-    hipLaunchKernelGGL(droppath_kernel, dim3((depth * 2 * B + 255) / 256), dim3(256), 0, s, scales, rates_dev, depth, B, seed, step);
+int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step, hipStream_t s) {
+    hipLaunchKernelGGL(droppath_kernel, dim3((depth * nbr * B + 255) / 256), dim3(256), 0, s, scales, rates_dev, depth, nbr, B, seed, step);
+    return uvit_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// WassersteinLoss forward + backward (distloss.py:13-30, 73-79):
+//   pos_r = sum (sig(o)-sig(t))^2 + sum (sqrt(sig(co)) - sqrt(sig(ct)))^2 ; u = pos / max(pos)
+//   loss  = lambda * sum_r softplus(u_r) / max_r softplus(u_r)
+// max_r u_r is exactly 1, so the second normaliser is the constant softplus(1) and carries no gradient;
+// the first one routes -sum_s g'(u_s) u_s / m to the arg-max row (autograd of `x / x.abs().max()`).
+// scratch: [0] max pos (float bits) [1] sum softplus [2] sum g' u [3] argmax row (int) ; pos[] from scratch+16
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sig_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(256)
+void wl_pos_kernel(const float* __restrict__ om, const float* __restrict__ oc, const float* __restrict__ tm,
+                   const float* __restrict__ tc, const int* __restrict__ count, float* __restrict__ scratch, int Mmax, int C) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= min(*count, Mmax)) return;
+    float acc = 0.f;
+    for (int i = lane; i < C; i += 64) {
+        const size_t o = (size_t)row * C + i;
+        const float d = sig_(om[o]) - sig_(tm[o]);
+        const float e = sqrtf(fmaxf(sig_(oc[o]), 1e-24f)) - sqrtf(fmaxf(sig_(tc[o]), 1e-24f));
+        acc += d * d + e * e;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) { scratch[16 + row] = acc; atomicMax((int*)scratch, __float_as_int(acc)); }
+}
+
+__global__ __launch_bounds__(256)
+void wl_sum_kernel(const int* __restrict__ count, float* __restrict__ scratch, int Mmax) {
+    const int n = min(*count, Mmax);
+    const float m = scratch[0];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const float pos = scratch[16 + r], u = pos / m;
+        s1 += log1pf(__expf(u));                       // softplus(u) = -log(sigmoid(-u))
+        s2 += sig_(u) * u;
+        if (pos == m) atomicMin((int*)scratch + 3, r);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(scratch + 1, s1); atomicAdd(scratch + 2, s2); }
+}
+
+__global__ __launch_bounds__(256)
+void wl_grad_kernel(const float* __restrict__ om, const float* __restrict__ oc, const float* __restrict__ tm,
+                    const float* __restrict__ tc, const int* __restrict__ count, const float* __restrict__ scratch,
+                    float lam, float* __restrict__ loss, bf16* __restrict__ dout_m, bf16* __restrict__ dout_c, int Mmax, int C) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = min(*count, Mmax);
+    const float F = 1.3132616875182228f;                // softplus(1)
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss, lam * scratch[1] / F);
+    if (row >= Mmax) return;
+    if (row >= n) {
+        for (int i = lane; i < C; i += 64) dout_c[(size_t)row * C + i] = f2bf(0.f);
+        return;
+    }
+    const float m = scratch[0], u = scratch[16 + row] / m;
+    float coef = sig_(u);
+    if (row == ((const int*)scratch)[3]) coef -= scratch[2];
+    coef *= lam / (F * m);
+    for (int i = lane; i < C; i += 64) {
+        const size_t o = (size_t)row * C + i;
+        const float a = sig_(om[o]), c1 = sig_(oc[o]), c2 = sig_(tc[o]);
+        const float gm = coef * 2.0f * (a - sig_(tm[o])) * a * (1.0f - a);
+        const float s1 = sqrtf(fmaxf(c1, 1e-24f)), s2 = sqrtf(fmaxf(c2, 1e-24f));
+        const float gc = coef * (s1 - s2) / s1 * c1 * (1.0f - c1);
+        dout_m[o] = f2bf(bf2f(dout_m[o]) + gm);         // on top of the SmoothL1 gradient already there
+        dout_c[o] = f2bf(gc);
+    }
+}
+
+int uvit_wasserstein_loss_launch(const float* out_m, const float* out_c, const float* tgt_m, const float* tgt_c, const int* count,
+                                 float lam, float loss_scale, float* scratch, float* loss, void* dout_m, void* dout_c,
+                                 int Mmax, int C, hipStream_t s) {
+    if (hipMemsetAsync(scratch, 0, 16 * sizeof(float), s) != hipSuccess) return UVIT_ERR_LAUNCH;
+    const int big = 0x7FFFFFFF;
+    (void)big;
+    hipLaunchKernelGGL(wl_pos_kernel, dim3((Mmax + 3) / 4), dim3(256), 0, s, out_m, out_c, tgt_m, tgt_c, count, scratch, Mmax, C);
+    // argmax slot starts at +inf (as int): set after the memset via a 4-byte memset pattern is not possible -> small fill
+    if (hipMemsetD32Async((hipDeviceptr_t)((int*)scratch + 3), 0x7FFFFFFF, 1, s) != hipSuccess) return UVIT_ERR_LAUNCH;
+    hipLaunchKernelGGL(wl_sum_kernel, dim3(64), dim3(256), 0, s, count, scratch, Mmax);
+    hipLaunchKernelGGL(wl_grad_kernel, dim3((Mmax + 3) / 4), dim3(256), 0, s, out_m, out_c, tgt_m, tgt_c, count, scratch,
+                       lam * loss_scale, loss, (bf16*)dout_m, (bf16*)dout_c, Mmax, C);
     return uvit_check_launch();
 }

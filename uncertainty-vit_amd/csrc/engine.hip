@@ -21,9 +21,11 @@
 // ------------------------------------------------------------------------------------------
 // layout
 // ------------------------------------------------------------------------------------------
-struct LayerOff { size_t n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2; };
+struct LayerOff { size_t n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2;
+                  size_t cqkvw, cqb, cvb, cprojw, cprojb; };   // two-stream model only
 struct Layout {
     size_t cls, mask_tok, pew, peb, relt, normw, normb, lmw, lmb;
+    size_t ccls, cmask_tok, cpew, cpeb, clmw, clmb;          // two-stream model only
     LayerOff L[UVIT_MAX_DEPTH];
     size_t n_total, n_decay;
     std::vector<uvit_layout_entry> entries;
@@ -58,22 +60,30 @@ static void build_layout(const uvit_config* c, Layout& lo) {
     };
     auto blk = [](int i, const char* s) { return "blocks." + std::to_string(i) + "." + s; };
     // ---- decay group: everything that is not 1-D, not *.bias, not in {pos_embed, cls_token} ----
+    const bool two = c->two_stream != 0;
     lo.mask_tok = add("mask_token", {1, 1, C}, 1);
+    if (two) lo.cmask_tok = add("cov_mask_token", {1, 1, C}, 1);
+    // 'cov_cls_token' is not in the no_weight_decay() skip list {'pos_embed','cls_token'} and is 3-D: decay group
+    if (two) lo.ccls = add("cov_cls_token", {1, 1, C}, 1);
     if (c->use_shared_rel_pos_bias) lo.relt = add("rel_pos_bias.relative_position_bias_table", {(2 * g - 1) * (2 * g - 1) + 3, c->num_heads}, 1);
     else lo.relt = (size_t)-1;
     lo.pew = add("patch_embed.proj.weight", {C, c->in_chans, c->patch_size, c->patch_size}, 1);
+    if (two) lo.cpew = add("cov_patch_embed.proj.weight", {C, c->in_chans, c->patch_size, c->patch_size}, 1);
     (void)Kpe;
     for (int i = 0; i < c->depth; ++i) {
         lo.L[i].qkvw = add(blk(i, "attn.qkv.weight"), {3 * C, C}, 1);
         lo.L[i].projw = add(blk(i, "attn.proj.weight"), {C, C}, 1);
+        if (two) lo.L[i].cprojw = add(blk(i, "attn.cov_proj.weight"), {C, C}, 1);
         lo.L[i].fc1w = add(blk(i, "mlp.fc1.weight"), {Hd, C}, 1);
         lo.L[i].fc2w = add(blk(i, "mlp.fc2.weight"), {C, Hd}, 1);
     }
     lo.lmw = add("lm_head.weight", {C, C}, 1);
+    if (two) lo.clmw = add("cov_lm_head.weight", {C, C}, 1);
     lo.n_decay = off;
     // ---- no-decay group ----
     lo.cls = add("cls_token", {1, 1, C}, 0);
     lo.peb = add("patch_embed.proj.bias", {C}, 0);
+    if (two) lo.cpeb = add("cov_patch_embed.proj.bias", {C}, 0);
     for (int i = 0; i < c->depth; ++i) {
         lo.L[i].g1 = add(blk(i, "gamma_1"), {C}, 0);
         lo.L[i].g2 = add(blk(i, "gamma_2"), {C}, 0);
@@ -81,7 +91,13 @@ static void build_layout(const uvit_config* c, Layout& lo) {
         lo.L[i].n1b = add(blk(i, "norm1.bias"), {C}, 0);
         lo.L[i].qb = add(blk(i, "attn.q_bias"), {C}, 0);
         lo.L[i].vb = add(blk(i, "attn.v_bias"), {C}, 0);
+        if (two) { lo.L[i].cqb = add(blk(i, "attn.cov_q_bias"), {C}, 0); lo.L[i].cvb = add(blk(i, "attn.cov_v_bias"), {C}, 0); }
         lo.L[i].projb = add(blk(i, "attn.proj.bias"), {C}, 0);
+        if (two) lo.L[i].cprojb = add(blk(i, "attn.cov_proj.bias"), {C}, 0);
+        // attn.cov_qkv.weight is never used by the reference's forward (modeling_finetune_dist.py:127 reuses qkv.weight):
+        // its .grad stays None, so torch's AdamW never touches it (no weight decay either).  It lives in the
+        // no-decay region with a zero gradient, which leaves it exactly constant; flag 2 = "frozen".
+        if (two) lo.L[i].cqkvw = add(blk(i, "attn.cov_qkv.weight"), {3 * C, C}, 2);
         lo.L[i].n2w = add(blk(i, "norm2.weight"), {C}, 0);
         lo.L[i].n2b = add(blk(i, "norm2.bias"), {C}, 0);
         lo.L[i].fc1b = add(blk(i, "mlp.fc1.bias"), {Hd}, 0);
@@ -90,12 +106,16 @@ static void build_layout(const uvit_config* c, Layout& lo) {
     lo.normw = add("norm.weight", {C}, 0);
     lo.normb = add("norm.bias", {C}, 0);
     lo.lmb = add("lm_head.bias", {C}, 0);
+    if (two) lo.clmb = add("cov_lm_head.bias", {C}, 0);
     lo.n_total = off;
 }
 
 // ------------------------------------------------------------------------------------------
 // engine
 // ------------------------------------------------------------------------------------------
+// Activation buffers are STACKED over the S streams of the model (S = 1 base model, S = 2 two-stream
+// "stochastic" model: mean rows [0, M), covariance rows [Mpad, Mpad + M)).  Ops whose weights are shared by the
+// streams (LayerNorms, fc1, fc2 weight gradient, qkv weight gradient, ...) run ONCE over the stacked rows.
 struct LayerActs {
     bf16 *ln1, *qkv, *attn, *projout, *ln2, *h, *a, *mlpout;
     float *mean1, *rstd1, *mean2, *rstd2, *lse;
@@ -106,6 +126,7 @@ struct uvit_engine {
     uvit_buffers buf;
     Layout lo;
     int B, P, N, NP, C, Hd, H, Kpe, M, Mpad, BP, BPpad, chunk, nchunk;
+    int S;                 // streams: 1 or 2
     int cur_B;             // batch of the last forward
     // workspace
     bf16* cols;
@@ -115,28 +136,32 @@ struct uvit_engine {
     LayerActs tacts;       // teacher scratch (nothing saved)
     float *tX[2], *tXM;
     int *rowidx, *count;
-    bf16 *normed, *dout, *dnormed, *dpatch;
-    float *meanF, *rstdF, *outputs, *targets;
+    bf16 *normed[2], *dout[2], *dnormed[2], *dpatch[2];
+    float *meanF[2], *rstdF[2], *outputs[2], *targets[2];
     float *biasP_s, *biasP_t, *slabs, *delta;
     float *dXa, *dXb;
     bf16 *dY1[2], *dY2[2], *dH[2], *dLN, *dAttn, *dqkv[2];   // [layer parity]: read by the wgrad stream while the next layer runs
     float *dp_scales, *dp_rates;
     float *loss, *gnorm; double* sumsq;
+    float* wl_scratch;     // Wasserstein loss: scalars + per-row distances
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
     float* grep;           // [NREP][no-decay region] replicated column-sum accumulators
     size_t n_nd;           // floats in the no-decay region
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
-    // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
     // second stream: teacher forward beside student forward; wgrad GEMMs beside the dgrad chain
     bool dual = true;
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_teacher = nullptr, ev_x[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_wdone[UVIT_MAX_DEPTH] = {};
+    // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
     size_t prof_used = 0;
+    // stacked-row helpers
+    size_t rows_all() const { return (size_t)(S - 1) * Mpad + M; }      // rows a stacked row-wise op covers
+    size_t rows_alloc() const { return (size_t)S * Mpad; }
 };
 
 struct Bump {
@@ -153,7 +178,7 @@ static size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 static void plan_workspace(uvit_engine* e, Bump& b) {
     const uvit_config& c = e->cfg;
-    const size_t Mp = e->Mpad, C = e->C, Hd = e->Hd, BPp = e->BPpad;
+    const size_t Mp = e->rows_alloc(), C = e->C, Hd = e->Hd, BPp = e->BPpad;
     auto acts = [&](LayerActs& a) {
         a.ln1 = b.take<bf16>(Mp * C); a.qkv = b.take<bf16>(Mp * 3 * C); a.attn = b.take<bf16>(Mp * C);
         a.projout = b.take<bf16>(Mp * C); a.ln2 = b.take<bf16>(Mp * C); a.h = b.take<bf16>(Mp * Hd);
@@ -167,10 +192,12 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     acts(e->tacts);
     e->tX[0] = b.take<float>(Mp * C); e->tX[1] = b.take<float>(Mp * C); e->tXM = b.take<float>(Mp * C);
     e->rowidx = b.take<int>(e->BP + 64); e->count = b.take<int>(64);
-    e->normed = b.take<bf16>(BPp * C); e->dout = b.take<bf16>(BPp * C); e->dnormed = b.take<bf16>(BPp * C);
-    e->dpatch = b.take<bf16>(BPp * C);
-    e->meanF = b.take<float>(BPp); e->rstdF = b.take<float>(BPp);
-    e->outputs = b.take<float>(BPp * C); e->targets = b.take<float>(BPp * C);
+    for (int st = 0; st < e->S; ++st) {
+        e->normed[st] = b.take<bf16>(BPp * C); e->dout[st] = b.take<bf16>(BPp * C); e->dnormed[st] = b.take<bf16>(BPp * C);
+        e->dpatch[st] = b.take<bf16>(BPp * C);
+        e->meanF[st] = b.take<float>(BPp); e->rstdF[st] = b.take<float>(BPp);
+        e->outputs[st] = b.take<float>(BPp * C); e->targets[st] = b.take<float>(BPp * C);
+    }
     const size_t bias_n = (size_t)e->H * e->NP * e->NP;
     e->biasP_s = b.take<float>(bias_n); e->biasP_t = b.take<float>(bias_n);
     e->slabs = b.take<float>(bias_n * e->nchunk);
@@ -181,9 +208,10 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
         e->dqkv[k] = b.take<bf16>(Mp * 3 * C);
     }
     e->dLN = b.take<bf16>(Mp * C); e->dAttn = b.take<bf16>(Mp * C);
-    e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->B); e->dp_rates = b.take<float>(c.depth);
+    e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->S * e->B); e->dp_rates = b.take<float>(c.depth);
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
-    e->tdesc = b.take<TransposeDesc>(5 * c.depth + 2);
+    e->wl_scratch = b.take<float>(16 + BPp);
+    e->tdesc = b.take<TransposeDesc>(7 * c.depth + 4);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
     e->grep = b.take<float>((size_t)NREP * e->n_nd);
 }
@@ -193,6 +221,7 @@ static void fill_dims(uvit_engine* e) {
     const int g = c.img_size / c.patch_size;
     e->B = c.batch; e->P = g * g; e->N = e->P + 1; e->NP = 208; e->C = c.embed_dim; e->Hd = c.mlp_hidden;
     e->H = c.num_heads; e->Kpe = c.in_chans * c.patch_size * c.patch_size;
+    e->S = c.two_stream ? 2 : 1;
     e->M = e->B * e->N; e->Mpad = (int)roundup(e->M, 128); e->BP = e->B * e->P; e->BPpad = (int)roundup(e->BP, 128);
     e->chunk = c.bias_chunk > 0 ? c.bias_chunk : 8;
     e->nchunk = (e->B + e->chunk - 1) / e->chunk;
@@ -200,6 +229,7 @@ static void fill_dims(uvit_engine* e) {
     Layout tmp_lo; build_layout(&e->cfg, tmp_lo);
     e->n_nd = tmp_lo.n_total - tmp_lo.n_decay;
 }
+
 
 extern "C" void uvit_engine_destroy(uvit_engine* e);
 extern "C" int uvit_version(void) { return UVIT_VERSION; }
@@ -264,8 +294,10 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     for (int i = 0; i < cfg->depth; ++i) {
         addT(e->lo.L[i].qkvw, 3 * e->C, e->C); addT(e->lo.L[i].projw, e->C, e->C);
         addT(e->lo.L[i].fc1w, e->Hd, e->C); addT(e->lo.L[i].fc2w, e->C, e->Hd);
+        if (e->S == 2) addT(e->lo.L[i].cprojw, e->C, e->C);
     }
     addT(e->lo.lmw, e->C, e->C);
+    if (e->S == 2) addT(e->lo.clmw, e->C, e->C);
     e->n_tdesc = (int)td.size(); e->n_ttiles = tiles;
     if (hipMemcpyAsync(e->dp_rates, rates.data(), rates.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(e->tdesc, td.data(), td.size() * sizeof(TransposeDesc), hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -344,36 +376,66 @@ extern "C" int uvit_engine_sync_shadows(uvit_engine* e, int which, uvit_stream s
 // ---- forward ----
 struct Weights { const float* f; const bf16* b; };
 
+// per-stream parameter offsets (stream 1 = covariance stream of the two-stream model)
+static size_t off_projw(const LayerOff& o, int st) { return st ? o.cprojw : o.projw; }
+static size_t off_projb(const LayerOff& o, int st) { return st ? o.cprojb : o.projb; }
+static size_t off_qb(const LayerOff& o, int st) { return st ? o.cqb : o.qb; }
+static size_t off_vb(const LayerOff& o, int st) { return st ? o.cvb : o.vb; }
+
+// drop-path multipliers: 2 draws per block (base) or 4 (two-stream: mean attn, mean mlp, cov attn, cov mlp;
+// modeling_finetune_dist.py:51-55)
+static const float* dp_ptr(uvit_engine* e, bool on, int l, int st, int branch, int Bc) {
+    if (!on) return nullptr;
+    const int nbr = 2 * e->S, k = e->S == 2 ? 2 * st + branch : branch;
+    return e->dp_scales + (size_t)(nbr * l + k) * Bc;
+}
+
 static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x_in, float* x_mid, float* x_out,
-                         LayerActs& a, bool save, const float* biasP, const float* dp1, const float* dp2,
-                         float pdrop, uint32_t seed, int Bc, hipStream_t s) {
+                         LayerActs& a, bool save, const float* biasP, bool dp_on, float pdrop, uint32_t seed, int Bc,
+                         hipStream_t s) {
     const LayerOff& o = e->lo.L[l];
-    const int M = Bc * e->N, C = e->C, Hd = e->Hd;
-    CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, M, C, e->cfg.ln_eps, s));
-    GemmEpi q; q.out = a.qkv; q.bias = w.f + o.qb; q.bias2 = w.f + o.vb; q.ldo = 3 * C;
-    CHECK(uvit_gemm_nt_launch(EPI_QKV, a.ln1, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
-    CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s));
-    GemmEpi p; p.out = x_mid; p.out2 = save ? a.projout : nullptr; p.bias = w.f + o.projb; p.gamma = w.f + o.g1;
-    p.resid = x_in; p.rowscale = dp1; p.ldo = C; p.tokens = e->N;
-    CHECK(uvit_gemm_nt_launch(EPI_RESID, a.attn, w.b + o.projw, M, C, C, C, C, &p, s));
-    CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, M, C, e->cfg.ln_eps, s));
+    const int M = Bc * e->N, C = e->C, Hd = e->Hd, S = e->S;
+    const size_t Mp = e->Mpad;                                   // row offset of stream 1
+    const int Mall = (int)((size_t)(S - 1) * Mp + M);
+    CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, Mall, C, e->cfg.ln_eps, s));
+    for (int st = 0; st < S; ++st) {     // same qkv.weight for both streams (modeling_finetune_dist.py:121,127)
+        GemmEpi q; q.out = a.qkv + st * Mp * 3 * C; q.bias = w.f + off_qb(o, st); q.bias2 = w.f + off_vb(o, st); q.ldo = 3 * C;
+        CHECK(uvit_gemm_nt_launch(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
+    }
+    if (S == 1) {
+        CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s));
+    } else {
+        CHECK(uvit_attn2_fwd_launch(a.qkv, a.qkv + Mp * 3 * C, biasP, a.attn, a.attn + Mp * C, a.lse, Bc, e->H, e->N, e->NP, 0.125f,
+                                    pdrop, seed, (uint32_t)l, s));
+    }
+    for (int st = 0; st < S; ++st) {
+        GemmEpi p; p.out = x_mid + st * Mp * C; p.out2 = save ? a.projout + st * Mp * C : nullptr; p.bias = w.f + off_projb(o, st);
+        p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
+        CHECK(uvit_gemm_nt_launch(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
+    }
+    CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
-    CHECK(uvit_gemm_nt_launch(EPI_GELU, a.ln2, w.b + o.fc1w, M, Hd, C, C, C, &f1, s));
+    CHECK(uvit_gemm_nt_launch(EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
     if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
-    GemmEpi f2; f2.out = x_out; f2.out2 = save ? a.mlpout : nullptr; f2.bias = w.f + o.fc2b; f2.gamma = w.f + o.g2;
-    f2.resid = x_mid; f2.rowscale = dp2; f2.ldo = C; f2.tokens = e->N;
-    CHECK(uvit_gemm_nt_launch(EPI_RESID, a.a, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
+    for (int st = 0; st < S; ++st) {
+        GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
+        f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
+        CHECK(uvit_gemm_nt_launch(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
+    }
     return UVIT_OK;
 }
 
-// patch embedding + token assembly into x0 (modeling_cyclical.py:171-192)
+// patch embedding + token assembly into x0 (modeling_cyclical.py:171-192; two-stream: modeling_cyclical_dist.py:106-130)
 static int embed(uvit_engine* e, const Weights& w, const int64_t* mask, float* x0, int Bc, hipStream_t s) {
-    GemmEpi pe; pe.out = x0; pe.bias = w.f + e->lo.peb; pe.mask = mask; pe.mask_token = w.f + e->lo.mask_tok;
-    pe.ldo = e->C; pe.patches = e->P;
-    CHECK(uvit_gemm_nt_launch(EPI_PATCH, e->cols, w.b + e->lo.pew, Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
-    CHECK(uvit_set_cls_launch(x0, w.f + e->lo.cls, nullptr, Bc, e->N, e->C, s));
+    for (int st = 0; st < e->S; ++st) {
+        float* x = x0 + (size_t)st * e->Mpad * e->C;
+        GemmEpi pe; pe.out = x; pe.bias = w.f + (st ? e->lo.cpeb : e->lo.peb); pe.mask = mask;
+        pe.mask_token = w.f + (st ? e->lo.cmask_tok : e->lo.mask_tok); pe.ldo = e->C; pe.patches = e->P;
+        CHECK(uvit_gemm_nt_launch(EPI_PATCH, e->cols, w.b + (st ? e->lo.cpew : e->lo.pew), Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
+        CHECK(uvit_set_cls_launch(x, w.f + (st ? e->lo.ccls : e->lo.cls), nullptr, Bc, e->N, e->C, s));
+    }
     return UVIT_OK;
 }
 
@@ -389,7 +451,7 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
                                     e->H, e->N, e->NP, s));
     const bool dp_on = dropout && !teacher && e->cfg.drop_path_rate > 0.f;
     const float pdrop = (dropout && !teacher) ? e->cfg.attn_drop_rate : 0.f;
-    if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, Bc, seed, it, s));
+    if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, 2 * e->S, Bc, seed, it, s));
     const uint32_t aseed = uvit_hash32(seed ^ (it * 0x85EBCA6Bu + 0x1234567u));
     if (!teacher) { e->last_dropout = dropout; e->last_seed = aseed; e->last_it = it; }
     const bool use_saved = !teacher || !hp_targets;   // drop-in forward keeps every layer for either weight set
@@ -397,26 +459,27 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
     CHECK(embed(e, w, mask, x0, Bc, s));
     int n_t = 0;
     for (int l = 0; l < e->cfg.depth; ++l) {
-        const float* dp1 = dp_on ? e->dp_scales + (size_t)(2 * l) * Bc : nullptr;
-        const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * Bc : nullptr;
         if (use_saved) {
-            CHECK(forward_layer(e, w, l, e->X[l], e->XM[l], e->X[l + 1], e->acts[l], save_student && !teacher, biasP, dp1, dp2,
+            CHECK(forward_layer(e, w, l, e->X[l], e->XM[l], e->X[l + 1], e->acts[l], save_student && !teacher, biasP, dp_on,
                                 pdrop, aseed, Bc, s));
         } else {
             float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
-            CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, nullptr, nullptr, 0.f, 0, Bc, s));
+            CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s));
             bool is_t = false;
             for (int k = 0; k < hp_targets->n_target_layers; ++k) is_t |= hp_targets->target_layers[k] == l;
             if (is_t) {
                 if (!hp_targets->target_layer_norm_last) return UVIT_ERR_ARG;
-                CHECK(uvit_target_accum_launch(xout, e->rowidx, e->count, e->targets, n_t == 0, Bc * e->P, e->C, 1e-5f, s));
+                for (int st = 0; st < e->S; ++st)
+                    CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
+                                                   Bc * e->P, e->C, 1e-5f, s));
                 ++n_t;
             }
         }
     }
     if (teacher && hp_targets) {
         if (n_t == 0) return UVIT_ERR_ARG;
-        CHECK(uvit_target_finalize_launch(e->targets, e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
+        for (int st = 0; st < e->S; ++st)
+            CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
     }
     e->cur_B = Bc;
     return UVIT_OK;
@@ -430,33 +493,37 @@ extern "C" int uvit_engine_forward_features(uvit_engine* e, int which, const flo
     return run_forward(e, which, images, mask, batch, false, train_dropout != 0, seed, it, nullptr, false, s);
 }
 
-static int head_forward(uvit_engine* e, const Weights& w, int Bc, bool all_tokens, float* out, hipStream_t s) {
+// final norm (shared) + drop cls + masked-row gather + per-stream head (modeling_cyclical.py:207,215-225)
+static int head_forward(uvit_engine* e, const Weights& w, int Bc, int st, bool all_tokens, float* out, hipStream_t s) {
     const int BP = Bc * e->P;
+    const float* x = e->X[e->cfg.depth] + (size_t)st * e->Mpad * e->C;
+    const size_t lmw = st ? e->lo.clmw : e->lo.lmw, lmb = st ? e->lo.clmb : e->lo.lmb;
     if (all_tokens) {
-        // every patch row: identity index list b*N+1+p built by compacting an all-ones mask is avoided --
         // normalise all tokens, then run the head on the patch rows of each sample
-        CHECK(uvit_ln_fwd_launch(e->X[e->cfg.depth], w.f + e->lo.normw, w.f + e->lo.normb, e->acts[0].ln1, e->acts[0].mean1,
-                                 e->acts[0].rstd1, Bc * e->N, e->C, e->cfg.ln_eps, s));
+        CHECK(uvit_ln_fwd_launch(x, w.f + e->lo.normw, w.f + e->lo.normb, e->acts[0].ln1, e->acts[0].mean1, e->acts[0].rstd1,
+                                 Bc * e->N, e->C, e->cfg.ln_eps, s));
         for (int b = 0; b < Bc; ++b) {
-            GemmEpi h; h.out = out + (size_t)b * e->P * e->C; h.bias = w.f + e->lo.lmb; h.ldo = e->C;
-            CHECK(uvit_gemm_nt_launch(EPI_F32, e->acts[0].ln1 + ((size_t)b * e->N + 1) * e->C, w.b + e->lo.lmw, e->P, e->C, e->C,
+            GemmEpi h; h.out = out + (size_t)b * e->P * e->C; h.bias = w.f + lmb; h.ldo = e->C;
+            CHECK(uvit_gemm_nt_launch(EPI_F32, e->acts[0].ln1 + ((size_t)b * e->N + 1) * e->C, w.b + lmw, e->P, e->C, e->C,
                                       e->C, e->C, &h, s));
         }
         return UVIT_OK;
     }
-    CHECK(uvit_ln_fwd_gather_launch(e->X[e->cfg.depth], e->rowidx, e->count, w.f + e->lo.normw, w.f + e->lo.normb, e->normed,
-                                    e->meanF, e->rstdF, BP, e->C, e->cfg.ln_eps, s));
-    GemmEpi h; h.out = out; h.bias = w.f + e->lo.lmb; h.ldo = e->C;
-    CHECK(uvit_gemm_nt_launch(EPI_F32, e->normed, w.b + e->lo.lmw, BP, e->C, e->C, e->C, e->C, &h, s));
+    CHECK(uvit_ln_fwd_gather_launch(x, e->rowidx, e->count, w.f + e->lo.normw, w.f + e->lo.normb, e->normed[st], e->meanF[st],
+                                    e->rstdF[st], BP, e->C, e->cfg.ln_eps, s));
+    GemmEpi h; h.out = out; h.bias = w.f + lmb; h.ldo = e->C;
+    CHECK(uvit_gemm_nt_launch(EPI_F32, e->normed[st], w.b + lmw, BP, e->C, e->C, e->C, e->C, &h, s));
     return UVIT_OK;
 }
 
 extern "C" int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float* out, int32_t* count_dev, uvit_stream stream) {
     if (!e || !out) return UVIT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const bool teacher = which == 1;
+    const bool teacher = (which & 1) != 0;
+    const int st = (which >> 1) & 1;                     // bit 1 selects the covariance stream of the two-stream model
+    if (st >= e->S) return UVIT_ERR_ARG;
     Weights w{teacher ? e->buf.ema : e->buf.params, (const bf16*)(teacher ? e->buf.ema_bf16 : e->buf.params_bf16)};
-    CHECK(head_forward(e, w, e->cur_B, all_tokens != 0, out, s));
+    CHECK(head_forward(e, w, e->cur_B, st, all_tokens != 0, out, s));
     if (count_dev && !all_tokens) HIPCHECK(hipMemcpyAsync(count_dev, e->count, sizeof(int), hipMemcpyDeviceToDevice, s));
     return UVIT_OK;
 }
@@ -464,12 +531,17 @@ extern "C" int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float
 extern "C" void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer) {
     if (!e || !name) return nullptr;
     const std::string n(name);
+    const size_t cov = (size_t)e->Mpad * e->C;           // element offset of the covariance stream in stacked buffers
     if (n == "x" && layer >= 0 && layer <= e->cfg.depth) return e->X[layer];
     if (n == "xm" && layer >= 0 && layer < e->cfg.depth) return e->XM[layer];
+    if (n == "x_cov" && e->S == 2 && layer >= 0 && layer <= e->cfg.depth) return e->X[layer] + cov;
+    if (n == "xm_cov" && e->S == 2 && layer >= 0 && layer < e->cfg.depth) return e->XM[layer] + cov;
     if (n == "loss") return e->loss;
     if (n == "grad_norm") return e->gnorm;
-    if (n == "targets") return e->targets;
-    if (n == "outputs") return e->outputs;
+    if (n == "targets") return e->targets[0];
+    if (n == "outputs") return e->outputs[0];
+    if (n == "targets_cov" && e->S == 2) return e->targets[1];
+    if (n == "outputs_cov" && e->S == 2) return e->outputs[1];
     if (n == "count") return e->count;
     if (n == "dx") return e->dXa;
     return nullptr;
@@ -482,7 +554,6 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     hipStream_t s = (hipStream_t)stream;
     const int Bc = e->B, BP = e->BP, C = e->C;
     Layout& lo = e->lo;
-    // zero the accumulated (atomic) gradient ranges + step scalars
     // every gradient is accumulated (split-K wgrad atomics, bias/LN/gamma column sums): zero the arena once
     HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), s));
     HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), s));
@@ -499,22 +570,29 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_teacher, ts));
     CHECK(run_forward(e, 0, images, mask, Bc, true, hp->train_dropout != 0, hp->seed, hp->it, nullptr, true, s));
     Weights w{e->buf.params, (const bf16*)e->buf.params_bf16};
-    CHECK(head_forward(e, w, Bc, false, e->outputs, s));
+    for (int st = 0; st < e->S; ++st) CHECK(head_forward(e, w, Bc, st, false, e->outputs[st], s));
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_teacher, 0));
-    // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163
+    // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163 (+ WassersteinLoss for the two-stream model, :152-161)
     const float ls = hp->loss_scale == -1.0f ? 1.0f : hp->loss_scale;
-    CHECK(uvit_smooth_l1_launch(e->outputs, e->targets, e->count, hp->l1_beta, hp->l2_loss, ls, e->loss, e->dout, BP, C, s));
-    // lm_head backward
+    CHECK(uvit_smooth_l1_launch(e->outputs[0], e->targets[0], e->count, hp->l1_beta, hp->l2_loss, ls, e->loss, e->dout[0], BP, C, s));
+    if (e->S == 2)
+        CHECK(uvit_wasserstein_loss_launch(e->outputs[0], e->outputs[1], e->targets[0], e->targets[1], e->count, hp->lambda_pretraining,
+                                           ls, e->wl_scratch, e->loss, e->dout[0], e->dout[1], BP, C, s));
+    // head backward
     float* g = e->buf.grads;
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
-    CHECK(uvit_colsum_launch(e->dout, C, 0, C, BP, RP(lo.lmb), NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dout, e->normed, e->BPpad, C, C, C, C, g + lo.lmw, C, 1, s));
-    GemmEpi d; d.out = e->dnormed; d.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout, wt + lo.lmw, BP, C, C, C, C, &d, s));
-    // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
-    HIPCHECK(hipMemsetAsync(e->dXa, 0, (size_t)e->M * C * sizeof(float), s));
-    CHECK(uvit_ln_bwd_scatter_launch(e->dnormed, e->X[e->cfg.depth], e->rowidx, e->count, e->meanF, e->rstdF,
-                                     e->buf.params + lo.normw, e->dXa, RP(lo.normw), RP(lo.normb), BP, C, NREP, e->n_nd, s));
+    HIPCHECK(hipMemsetAsync(e->dXa, 0, e->rows_alloc() * C * sizeof(float), s));
+    for (int st = 0; st < e->S; ++st) {
+        const size_t lmw = st ? lo.clmw : lo.lmw, lmb = st ? lo.clmb : lo.lmb;
+        CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, BP, RP(lmb), NREP, e->n_nd, s));
+        CHECK(uvit_gemm_tn_launch(e->dout[st], e->normed[st], e->BPpad, C, C, C, C, g + lmw, C, 1, s));
+        GemmEpi d; d.out = e->dnormed[st]; d.ldo = C;
+        CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout[st], wt + lmw, BP, C, C, C, C, &d, s));
+        // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
+        CHECK(uvit_ln_bwd_scatter_launch(e->dnormed[st], e->X[e->cfg.depth] + (size_t)st * e->Mpad * C, e->rowidx, e->count,
+                                         e->meanF[st], e->rstdF[st], e->buf.params + lo.normw, e->dXa + (size_t)st * e->Mpad * C,
+                                         RP(lo.normw), RP(lo.normb), BP, C, NREP, e->n_nd, s));
+    }
     return UVIT_OK;
 }
 
@@ -524,13 +602,15 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     hipStream_t s = (hipStream_t)stream;
     const LayerOff& o = e->lo.L[l];
     LayerActs& a = e->acts[l];
-    const int M = e->M, Mp = (int)roundup(e->M, 64), C = e->C, Hd = e->Hd;
+    const int M = e->M, C = e->C, Hd = e->Hd, S = e->S;
+    const size_t Mp = e->Mpad;
+    const int Mall = (int)e->rows_all();                      // stacked rows of a row-wise op
+    const int Mred = (int)roundup(e->rows_all(), 64);          // stacked reduction length of a wgrad (pad rows are zero in dY)
+    const int Mred1 = (int)roundup(M, 64);                     // one stream
     float* g = e->buf.grads;
     const float* pf = e->buf.params;
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
     const bool dp_on = e->last_dropout && e->cfg.drop_path_rate > 0.f;
-    const float* dp1 = dp_on ? e->dp_scales + (size_t)(2 * l) * e->B : nullptr;
-    const float* dp2 = dp_on ? e->dp_scales + (size_t)(2 * l + 1) * e->B : nullptr;
     const float pdrop = e->last_dropout ? e->cfg.attn_drop_rate : 0.f;
     // wgrad GEMMs + bias column sums go to the second stream; the dgrad chain stays on `s`.  The
     // gradient buffers they read are double-buffered by layer parity; before reusing a parity the
@@ -545,37 +625,51 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     };
     if (e->dual && l + 2 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 2], 0));
     bf16 *dY1 = e->dY1[par], *dY2 = e->dY2[par], *dH = e->dH[par], *dqkv = e->dqkv[par];
-    // --- MLP branch: x_out = x_mid + dp2 * gamma2 * (fc2(gelu(fc1(ln2(x_mid)))))
-    CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp2, dY1, RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
+    // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
+    for (int st = 0; st < S; ++st)
+        CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
+                                 RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
     CHECK(handoff(0));
-    CHECK(uvit_gemm_tn_launch(dY1, a.a, Mp, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+    CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
     GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
-    CHECK(uvit_gemm_nt_launch(EPI_DGELU, dY1, wt + o.fc2w, M, Hd, C, C, C, &d1, s));
+    CHECK(uvit_gemm_nt_launch(EPI_DGELU, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));
     CHECK(handoff(1));
-    CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, M, RP(o.fc1b), NREP, e->n_nd, ws));
-    CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mp, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
+    CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));
+    CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, M, C, Hd, Hd, Hd, &d2, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), M, C, NREP, e->n_nd, s));
-    // --- attention branch: x_mid = x_in + dp1 * gamma1 * proj(attn(ln1(x_in)))
-    CHECK(uvit_ls_bwd_launch(e->dXb, a.projout, pf + o.g1, dp1, dY2, RP(o.g1), RP(o.projb), M, C, e->N, NREP, e->n_nd, s));
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
+    // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
+    for (int st = 0; st < S; ++st)
+        CHECK(uvit_ls_bwd_launch(e->dXb + st * Mp * C, a.projout + st * Mp * C, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + st * Mp * C,
+                                 RP(o.g1), RP(off_projb(o, st)), M, C, e->N, NREP, e->n_nd, s));
     CHECK(handoff(2));
-    CHECK(uvit_gemm_tn_launch(dY2, a.attn, Mp, C, C, C, C, g + o.projw, C, 1, ws));
-    GemmEpi d3; d3.out = e->dAttn; d3.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2, wt + o.projw, M, C, C, C, C, &d3, s));
+    for (int st = 0; st < S; ++st) {
+        CHECK(uvit_gemm_tn_launch(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
+        GemmEpi d3; d3.out = e->dAttn + st * Mp * C; d3.ldo = C;
+        CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), M, C, C, C, C, &d3, s));
+    }
     const float* biasP = e->biasP_s;
-    CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr,
-                               e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed,
-                               (uint32_t)l, s));
+    float* slabs = e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr;
+    if (S == 1) {
+        CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, slabs, e->slab_started ? 1 : 0, e->chunk,
+                                   e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+    } else {
+        CHECK(uvit_attn2_bwd_launch(a.qkv, a.qkv + Mp * 3 * C, a.attn, a.attn + Mp * C, e->dAttn, e->dAttn + Mp * C, biasP, a.lse,
+                                    e->delta, dqkv, dqkv + Mp * 3 * C, slabs, e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N,
+                                    e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+    }
     e->slab_started = true;
     CHECK(handoff(3));
-    CHECK(uvit_colsum_launch(dqkv, 3 * C, 0, C, M, RP(o.qb), NREP, e->n_nd, ws));
-    CHECK(uvit_colsum_launch(dqkv, 3 * C, 2 * C, C, M, RP(o.vb), NREP, e->n_nd, ws));
-    CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mp, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
+    for (int st = 0; st < S; ++st) {
+        CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
+        CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));
+    }
+    CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, M, C, 3 * C, 3 * C, 3 * C, &d4, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), M, C, NREP, e->n_nd, s));
+    CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
+    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), Mall, C, NREP, e->n_nd, s));
     return UVIT_OK;
 }
 
@@ -585,10 +679,13 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     Layout& lo = e->lo;
     float* g = e->buf.grads;
     const int C = e->C, BP = e->BP;
-    // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
-    CHECK(uvit_token_bwd_launch(e->dXa, e->mask_copy, e->dpatch, g + lo.cls, g + lo.mask_tok, e->B, e->P, C, s));
-    CHECK(uvit_colsum_launch(e->dpatch, C, 0, C, BP, RP(lo.peb), NREP, e->n_nd, s));
-    CHECK(uvit_gemm_tn_launch(e->dpatch, e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + lo.pew, e->Kpe, 1, s));
+    for (int st = 0; st < e->S; ++st) {
+        // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
+        CHECK(uvit_token_bwd_launch(e->dXa + (size_t)st * e->Mpad * C, e->mask_copy, e->dpatch[st], g + (st ? lo.ccls : lo.cls),
+                                    g + (st ? lo.cmask_tok : lo.mask_tok), e->B, e->P, C, s));
+        CHECK(uvit_colsum_launch(e->dpatch[st], C, 0, C, BP, RP(st ? lo.cpeb : lo.peb), NREP, e->n_nd, s));
+        CHECK(uvit_gemm_tn_launch(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
+    }
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed
@@ -596,6 +693,7 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
     return UVIT_OK;
 }
+
 
 extern "C" int uvit_step_wait_layer_grads(uvit_engine* e, int layer, uvit_stream stream) {
     if (!e || layer < 0 || layer >= e->cfg.depth) return UVIT_ERR_ARG;
@@ -662,6 +760,19 @@ extern "C" int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* 
     if (!qkv || !o_fwd || !d_o || !lse || !delta || !dqkv) return UVIT_ERR_ARG;
     return uvit_attn_bwd_launch(qkv, o_fwd, d_o, biasP, lse, delta, dqkv, slab, acc, chunk, B, H, N, NP, scale, p_drop, seed, layer, S(st));
 }
+extern "C" int uvit_op_attn2_fwd(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse, int B,
+                                 int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
+    if (!qkv_m || !qkv_c || !out_m || !out_c || !lse) return UVIT_ERR_ARG;
+    return uvit_attn2_fwd_launch(qkv_m, qkv_c, biasP, out_m, out_c, lse, B, H, N, NP, scale, p_drop, seed, layer, S(st));
+}
+extern "C" int uvit_op_attn2_bwd(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
+                                 const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* slab, int acc,
+                                 int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer,
+                                 uvit_stream st) {
+    if (!qkv_m || !qkv_c || !o_m || !o_c || !d_m || !d_c || !lse || !delta || !dqkv_m || !dqkv_c) return UVIT_ERR_ARG;
+    return uvit_attn2_bwd_launch(qkv_m, qkv_c, o_m, o_c, d_m, d_c, biasP, lse, delta, dqkv_m, dqkv_c, slab, acc, chunk, B, H, N, NP,
+                                 scale, p_drop, seed, layer, S(st));
+}
 extern "C" int uvit_op_relpos_gather(const float* t, const int32_t* idx, float* biasP, int H, int N, int NP, uvit_stream st) {
     return uvit_relpos_gather_launch(t, idx, biasP, H, N, NP, S(st));
 }
@@ -701,6 +812,6 @@ extern "C" int uvit_op_im2col(const float* img, void* cols, int B, int Cin, int 
     return uvit_im2col_launch(img, cols, B, Cin, S_, p, S(st));
 }
 extern "C" int uvit_op_droppath(float* sc, const float* rates, int depth, int B, uint32_t seed, uint32_t step, uvit_stream st) {
-    return uvit_droppath_launch(sc, rates, depth, B, seed, step, S(st));
+    return uvit_droppath_launch(sc, rates, depth, 2, B, seed, step, S(st));
 }
 extern "C" int uvit_op_cast_bf16(const float* src, void* dst, int64_t n, uvit_stream st) { return uvit_cast_bf16_launch(src, dst, (size_t)n, S(st)); }

@@ -35,8 +35,8 @@ __device__ __forceinline__ ColVals load_cols(const GemmEpi& e, int n, int N) {
     ColVals c;
     c.b = make_float4(0.f, 0.f, 0.f, 0.f);
     c.g = c.b;
-    if constexpr (MODE == EPI_QKV) {
-        // bias = cat(q_bias, 0, v_bias)  (modeling_finetune.py:149-151)
+    if constexpr (MODE == EPI_QKV || MODE == EPI_QKV_ELU) {
+        // bias = cat(q_bias, 0, v_bias)  (modeling_finetune.py:149-151; cov stream: modeling_finetune_dist.py:116-127)
         const int C = N / 3;
         if (n < C) c.b = *(const float4*)(e.bias + n);
         else if (n >= 2 * C) c.b = *(const float4*)(e.bias2 + (n - 2 * C));
@@ -75,6 +75,12 @@ __device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n, const 
     const size_t o = (size_t)m * e.ldo + n;
     if constexpr (MODE == EPI_BF16 || MODE == EPI_QKV) {
         bf16x4 v = {f2bf(acc[0] + cv.b.x), f2bf(acc[1] + cv.b.y), f2bf(acc[2] + cv.b.z), f2bf(acc[3] + cv.b.w)};
+        *(bf16x4*)((bf16*)e.out + o) = v;
+    } else if constexpr (MODE == EPI_QKV_ELU) {
+        // cov_qkv = ELU(x) + 1  (= x + 1 for x > 0, exp(x) otherwise)
+        const float x0 = acc[0] + cv.b.x, x1 = acc[1] + cv.b.y, x2 = acc[2] + cv.b.z, x3 = acc[3] + cv.b.w;
+        bf16x4 v = {f2bf(x0 > 0.f ? x0 + 1.f : __expf(x0)), f2bf(x1 > 0.f ? x1 + 1.f : __expf(x1)),
+                    f2bf(x2 > 0.f ? x2 + 1.f : __expf(x2)), f2bf(x3 > 0.f ? x3 + 1.f : __expf(x3))};
         *(bf16x4*)((bf16*)e.out + o) = v;
     } else if constexpr (MODE == EPI_F32) {
         *(float4*)((float*)e.out + o) = make_float4(acc[0] + cv.b.x, acc[1] + cv.b.y, acc[2] + cv.b.z, acc[3] + cv.b.w);
@@ -639,12 +645,12 @@ static void gemm_init_once() {
     if (g_attr_done) return;
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
-    allow_lds(gemm_nt_kernel<EPI_DGELU>);
+    allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
 #define ALLOW256(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES)
-    ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU);
+    ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU);
 #undef ALLOW256
 #define ALLOW2(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)
-    ALLOW2(EPI_BF16); ALLOW2(EPI_QKV); ALLOW2(EPI_GELU); ALLOW2(EPI_RESID); ALLOW2(EPI_F32); ALLOW2(EPI_PATCH); ALLOW2(EPI_DGELU);
+    ALLOW2(EPI_BF16); ALLOW2(EPI_QKV); ALLOW2(EPI_GELU); ALLOW2(EPI_RESID); ALLOW2(EPI_F32); ALLOW2(EPI_PATCH); ALLOW2(EPI_DGELU); ALLOW2(EPI_QKV_ELU);
 #undef ALLOW2
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     g_attr_done = true;
@@ -678,6 +684,7 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
         case EPI_F32: L(EPI_F32); break;
         case EPI_PATCH: L(EPI_PATCH); break;
         case EPI_DGELU: L(EPI_DGELU); break;
+        case EPI_QKV_ELU: if (N % 3) return UVIT_ERR_SHAPE; L(EPI_QKV_ELU); break;
         default: return UVIT_ERR_ARG;
     }
 #undef L

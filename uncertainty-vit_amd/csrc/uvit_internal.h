@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { EPI_BF16 = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_PATCH = 5, EPI_DGELU = 6 };
+enum { EPI_BF16 = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_PATCH = 5, EPI_DGELU = 6, EPI_QKV_ELU = 7 };
 
 struct GemmEpi {
     void* out = nullptr;             // bf16 or f32 [M, ldo]
@@ -36,6 +36,14 @@ int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* 
 int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                          float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H,
                          int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+
+// attention2.hip (two-stream Wasserstein attention)
+int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse,
+                          int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+int uvit_attn2_bwd_launch(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
+                          const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* dbias_slab,
+                          int accumulate_slab, int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
+                          uint32_t layer, hipStream_t s);
 
 // norm.hip
 int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y_bf16, float* mean, float* rstd,
@@ -71,8 +79,11 @@ int uvit_smooth_l1_launch(const float* out, const float* target, const int* coun
 int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf16, float* dcls, float* dmask_token,
                           int B, int P, int C, hipStream_t s);
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
-int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step,
+int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step,
                          hipStream_t s);
+int uvit_wasserstein_loss_launch(const float* out_m, const float* out_c, const float* tgt_m, const float* tgt_c, const int* count,
+                                 float lam, float loss_scale, float* scratch, float* loss, void* dout_m_bf16, void* dout_c_bf16,
+                                 int Mmax, int C, hipStream_t s);
 
 // optim.hip
 int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s);

@@ -42,7 +42,7 @@ class GradReducer:
             lo = lay[f"blocks.{i}.attn.qkv.weight"][0]
             hi = sum(lay[f"blocks.{i}.mlp.fc2.weight"])
             self.layer_ranges.append((lo, hi))
-        self.head_range = (lay["lm_head.weight"][0], sum(lay["lm_head.weight"]))
+        self.head_range = (lay["lm_head.weight"][0], model._n_decay)      # lm_head (+ cov_lm_head) weights end the decay region
         self.embed_range = (0, lay["blocks.0.attn.qkv.weight"][0])
         self.small_range = (model._n_decay, model._arena.numel())      # every no-decay tensor, one message
         self.pending = []
@@ -93,7 +93,7 @@ def native_step(engine, reducer, samples, mask, hp):
 
 
 def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
-                     post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True):
+                     post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5):
     hp = StepParams()
     for i, t in enumerate(target_layers):
         hp.target_layers[i] = int(t)
@@ -111,6 +111,7 @@ def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_
     hp.grad_scale = 1.0 / world
     hp.seed, hp.it = int(seed) & 0xFFFFFFFF, int(it) & 0xFFFFFFFF
     hp.train_dropout = int(bool(train_dropout))
+    hp.lambda_pretraining = float(lambda_pretraining)
     return hp
 
 
@@ -125,14 +126,16 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     print(' <<<<<<<< layer_results >>>>>>>>', layer_results)
     print(' <<<<<<<< var_w0, var_w1 >>>>>>>>', var_w0, var_w1)
     # flags whose arithmetic is not on the configured hot path are refused, never approximated
-    if stochastic:
-        raise NotImplementedError("--stochastic selects the two-stream model (dist_beit_base_patch16_224); not built yet (DESIGN.md)")
     if layer_results != 'end' or target_batch_norm or target_instance_norm or post_target_instance_norm or var_w0 > 0 \
             or not target_layer_norm_last:
         raise NotImplementedError("only layer_results='end' with target layer-norm (README.md:11-25 recipe) is native")
     model.train()
     net = _unwrap(model)
     teacher = model_ema.module
+    if bool(stochastic) != bool(getattr(net, "_two_stream", False)):
+        # the reference unpacks (mean, cov) pairs when stochastic (engine_for_cyclical.py:70,126): only the two-stream
+        # model (dist_beit_base_patch16_224) returns them -- SURVEY.md F8
+        raise ValueError("stochastic=True needs the two-stream model (dist_beit_base_patch16_224) and vice versa")
     metric_logger = utils.MetricLogger(delimiter="  ")
     metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
     metric_logger.add_meter('min_lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
@@ -177,7 +180,7 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
         if not do_ema:
             cur_decay = 0
         hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
-                              post_target_layer_norm, cur_decay, do_ema, world, seed, it)
+                              post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining)
         native_step(engine, reducer, samples, mask, hp)
         optimizer.step_count += 1
 

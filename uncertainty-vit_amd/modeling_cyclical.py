@@ -22,8 +22,8 @@ import torch.nn as nn
 from . import native
 from .native import Buffers, Config, LayoutEntry, check, cur_stream, lib, ptr
 
-__all__ = ["beit_base_patch16_224", "beit_large_patch16_224", "create_model", "register_model",
-           "VisionTransformerForCyclicalTraining"]
+__all__ = ["beit_base_patch16_224", "dist_beit_base_patch16_224", "beit_large_patch16_224", "create_model", "register_model",
+           "VisionTransformerForCyclicalTraining", "DistVisionTransformerForCyclicalTraining"]
 
 
 def _cfg(url="", **kwargs):
@@ -127,6 +127,8 @@ class NativeEngine:
 
 
 class VisionTransformerForCyclicalTraining(nn.Module):
+    _two_stream = False      # True in DistVisionTransformerForCyclicalTraining
+
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
                  qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer=None,
                  init_values=None, attn_head_dim=None, use_abs_pos_emb=True, use_rel_pos_bias=False,
@@ -177,14 +179,19 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         for i in range(L.uvit_layout_count(C.byref(cfg))):
             e = LayoutEntry()
             check(L.uvit_layout_get(C.byref(cfg), i, C.byref(e)), "uvit_layout_get")
-            self._layout.append((e.name.decode(), int(e.offset), int(e.numel), tuple(e.shape[:e.ndim]), bool(e.decay)))
+            self._layout.append((e.name.decode(), int(e.offset), int(e.numel), tuple(e.shape[:e.ndim]), int(e.decay)))
         self.blocks = nn.ModuleList()
         for _ in range(depth):
             blk = _Holder()
             blk.norm1, blk.norm2, blk.attn, blk.mlp = _Holder(), _Holder(), _Holder(), _Holder()
             blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2 = _Holder(), _Holder(), _Holder(), _Holder()
+            if self._two_stream:
+                blk.attn.cov_qkv, blk.attn.cov_proj = _Holder(), _Holder()
             self.blocks.append(blk)
         self.norm, self.lm_head = _Holder(), _Holder()
+        if self._two_stream:
+            self.cov_patch_embed = _PatchEmbedInfo(img_size, patch_size)
+            self.cov_lm_head = _Holder()
         if use_shared_rel_pos_bias:
             self.rel_pos_bias = _Holder()
             self.rel_pos_bias.window_size = self.patch_embed.patch_shape
@@ -195,7 +202,10 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         if use_shared_rel_pos_bias:
             self.rel_pos_bias.register_buffer("relative_position_index", relative_position_index(ws))
         self._order_like_reference()
-        self._init_weights()
+        if self._two_stream:
+            self._init_weights_dist()
+        else:
+            self._init_weights()
         self._engine = None
         self.default_cfg = _cfg()
 
@@ -203,7 +213,7 @@ class VisionTransformerForCyclicalTraining(nn.Module):
     def _native_config(self, batch):
         return Config(self.img_size, self.patch_embed.patch_size[0], self.in_chans, self.embed_dim, self.depth,
                       self.num_heads, self.mlp_hidden, 1 if getattr(self, "rel_pos_bias", True) is not None else 0, 0,
-                      batch, self.ln_eps, self.attn_drop_rate, self.drop_path_rate, 0)
+                      batch, self.ln_eps, self.attn_drop_rate, self.drop_path_rate, 0, 1 if self._two_stream else 0)
 
     def _owner(self, name):
         mod = self
@@ -222,13 +232,14 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         (ModelEmaV2 zips state-dict VALUES by position, engine_for_cyclical.py:183)."""
         def reorder(mod, order):
             mod._parameters = {k: mod._parameters[k] for k in order if k in mod._parameters}
-        reorder(self, ["cls_token", "mask_token"])
-        self._modules = {k: self._modules[k] for k in ("patch_embed", "rel_pos_bias", "blocks", "norm", "lm_head")
-                         if k in self._modules}
+        reorder(self, ["cls_token", "cov_cls_token", "mask_token", "cov_mask_token"])
+        self._modules = {k: self._modules[k] for k in ("patch_embed", "cov_patch_embed", "rel_pos_bias", "blocks", "norm",
+                                                       "lm_head", "cov_lm_head") if k in self._modules}
         for blk in self.blocks:
             reorder(blk, ["gamma_1", "gamma_2"])
             blk._modules = {k: blk._modules[k] for k in ("norm1", "attn", "norm2", "mlp")}
-            reorder(blk.attn, ["q_bias", "v_bias"])
+            reorder(blk.attn, ["q_bias", "v_bias", "cov_q_bias", "cov_v_bias"])
+            blk.attn._modules = {k: blk.attn._modules[k] for k in ("qkv", "cov_qkv", "proj", "cov_proj") if k in blk.attn._modules}
 
     def _rebind(self):
         for name, off, numel, shape, _ in self._layout:
@@ -299,6 +310,30 @@ class VisionTransformerForCyclicalTraining(nn.Module):
                 sd[f"blocks.{i}.mlp.fc2.weight"].div_(math.sqrt(2.0 * (i + 1)))
         self._shadows_stale = True
 
+    def _init_weights_dist(self):
+        """modeling_cyclical_dist.py:62-90: cls tokens trunc-normal (timm default bounds +-2), Linear weights
+        trunc-normal(.02), biases 0, LayerNorm (1, 0); mask tokens stay 0 and the patch-embedding convs keep
+        nn.Conv2d's default init (neither is touched by the reference's _init_weights); proj / cov_proj / fc2
+        rescaled by 1/sqrt(2*(layer+1))."""
+        sd = dict(self.named_parameters())
+        with torch.no_grad():
+            for name, p in sd.items():
+                if name.endswith("gamma_1") or name.endswith("gamma_2"):
+                    p.fill_(self.init_values)
+                elif "norm" in name and name.endswith("weight"):
+                    p.fill_(1.0)
+                elif "patch_embed" in name:
+                    bound = 1.0 / math.sqrt(self.in_chans * self.patch_embed.patch_size[0] ** 2)
+                    p.uniform_(-bound, bound)
+                elif name.endswith("relative_position_bias_table") or name.endswith("bias") or "mask_token" in name:
+                    p.zero_()
+                elif name.endswith("weight") or name.endswith("cls_token"):
+                    p.normal_(0.0, 0.02).clamp_(-2.0, 2.0)
+            for i in range(self.depth):
+                for n in ("attn.proj.weight", "attn.cov_proj.weight", "mlp.fc2.weight"):
+                    sd[f"blocks.{i}.{n}"].div_(math.sqrt(2.0 * (i + 1)))
+        self._shadows_stale = True
+
     @torch.jit.ignore
     def no_weight_decay(self):
         return {"pos_embed", "cls_token"}
@@ -335,6 +370,13 @@ class VisionTransformerForCyclicalTraining(nn.Module):
                                                  C.c_uint32(getattr(self, "_fwd_count", 0)), cur_stream()), "forward_features")
         self._fwd_count = getattr(self, "_fwd_count", 0) + 1
         N = self.patch_embed.num_patches + 1
+        if self._two_stream:
+            if layer_results == "end":
+                return ([e.ws_tensor("x", i + 1, (B, N, self.embed_dim)).clone() for i in range(self.depth)],
+                        [e.ws_tensor("x_cov", i + 1, (B, N, self.embed_dim)).clone() for i in range(self.depth)])
+            if layer_results:
+                raise NotImplementedError("the two-stream model only collects layer_results='end' (modeling_cyclical_dist.py:136-139)")
+            return e
         if layer_results == "end":
             return [e.ws_tensor("x", i + 1, (B, N, self.embed_dim)).clone() for i in range(self.depth)]
         if layer_results == "fc":
@@ -347,14 +389,17 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         engine_for_cyclical.train_one_epoch, whose backward is native as well."""
         out = self.forward_features(x, bool_masked_pos=bool_masked_pos, layer_results=layer_results)
         if layer_results:
+            if self._two_stream:
+                return [z[:, 1:] for z in out[0]], [z[:, 1:] for z in out[1]]
             return [z[:, 1:] for z in out]
         e, B, P = out, x.shape[0], self.patch_embed.num_patches
-        buf = torch.empty(B * P, self.embed_dim, device=x.device)
-        cnt = torch.zeros(1, dtype=torch.int32, device=x.device)
-        check(lib().uvit_engine_head(e.h, 0, 1 if return_all_tokens else 0, ptr(buf), ptr(cnt), cur_stream()), "head")
-        if return_all_tokens:
-            return buf.view(B, P, self.embed_dim)
-        return buf[: int(cnt.item())]
+        res = []
+        for st in range(2 if self._two_stream else 1):       # stream 1: cov_lm_head on the covariance stream
+            buf = torch.empty(B * P, self.embed_dim, device=x.device)
+            cnt = torch.zeros(1, dtype=torch.int32, device=x.device)
+            check(lib().uvit_engine_head(e.h, 2 * st, 1 if return_all_tokens else 0, ptr(buf), ptr(cnt), cur_stream()), "head")
+            res.append(buf.view(B, P, self.embed_dim) if return_all_tokens else buf[: int(cnt.item())])
+        return tuple(res) if self._two_stream else res[0]
 
 
 # ---- registry: timm.models.registry / create_model as used at run_cyclical.py:289-302 ----
@@ -372,13 +417,21 @@ def create_model(model_name, pretrained=False, **kwargs):
     return _REGISTRY[model_name](pretrained=pretrained, pretrained_cfg=None, pretrained_cfg_overlay=None, **kwargs)
 
 
-def _build(pretrained, kwargs, **arch):
+class DistVisionTransformerForCyclicalTraining(VisionTransformerForCyclicalTraining):
+    """Two-stream (mean, covariance) model of modeling_cyclical_dist.py:14-165 with Wasserstein attention
+    (modeling_finetune_dist.py:61-179).  forward() returns 2-tuples (modeling_cyclical_dist.py:146-165).
+    The reference quirks are kept: the covariance QKV uses `attn.qkv.weight`, `attn.cov_qkv.weight` is a dead
+    parameter (no gradient, still EMA-averaged), norms / mlp / gammas are shared, no position embedding."""
+    _two_stream = True
+
+
+def _build(pretrained, kwargs, cls=None, **arch):
     kwargs.pop("pretrained_cfg", None)
     kwargs.pop("pretrained_cfg_overlay", None)
     kwargs.pop("num_classes", None)
     init_ckpt = kwargs.pop("init_ckpt", None)
-    model = VisionTransformerForCyclicalTraining(patch_size=16, mlp_ratio=4, qkv_bias=True,
-                                                 norm_layer=partial(nn.LayerNorm, eps=1e-6), **arch, **kwargs)
+    model = (cls or VisionTransformerForCyclicalTraining)(patch_size=16, mlp_ratio=4, qkv_bias=True,
+                                                          norm_layer=partial(nn.LayerNorm, eps=1e-6), **arch, **kwargs)
     if pretrained:
         model.load_state_dict(torch.load(init_ckpt, map_location="cpu")["model"])
     return model
@@ -388,6 +441,12 @@ def _build(pretrained, kwargs, **arch):
 def beit_base_patch16_224(pretrained=False, **kwargs):
     """modeling_cyclical.py:282-301."""
     return _build(pretrained, kwargs, embed_dim=768, depth=12, num_heads=12)
+
+
+@register_model
+def dist_beit_base_patch16_224(pretrained=False, **kwargs):
+    """modeling_cyclical.py:304-323: the model that returns (mean, cov) pairs, i.e. what `--stochastic` needs."""
+    return _build(pretrained, kwargs, cls=DistVisionTransformerForCyclicalTraining, embed_dim=768, depth=12, num_heads=12)
 
 
 @register_model

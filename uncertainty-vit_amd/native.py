@@ -30,7 +30,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads",
                                           "mlp_hidden", "use_shared_rel_pos_bias", "use_abs_pos_emb", "batch")] + \
                [("ln_eps", C.c_float), ("attn_drop_rate", C.c_float), ("drop_path_rate", C.c_float),
-                ("bias_chunk", C.c_int32)]
+                ("bias_chunk", C.c_int32), ("two_stream", C.c_int32)]
 
 
 class LayoutEntry(C.Structure):
@@ -50,7 +50,7 @@ class StepParams(C.Structure):
                 ("l1_beta", C.c_float), ("loss_scale", C.c_float), ("clip_grad", C.c_float), ("lr", C.c_float),
                 ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("opt_step", C.c_int32), ("ema_decay", C.c_float), ("do_ema", C.c_int32), ("grad_scale", C.c_float),
-                ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32)]
+                ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float)]
 
 
 class GemmEpilogue(C.Structure):
@@ -88,6 +88,8 @@ _PROTOTYPES = {
     "uvit_op_gemm_tn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "uvit_op_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
+    "uvit_op_attn2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
+    "uvit_op_attn2_bwd": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_relpos_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "uvit_op_relpos_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "uvit_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

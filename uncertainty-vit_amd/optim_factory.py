@@ -33,6 +33,8 @@ class ArenaAdamW:
         skip = model.no_weight_decay() if hasattr(model, "no_weight_decay") else ()
         groups, self.group_names = get_parameter_groups(model, weight_decay, skip)
         # the arena layout must agree with the reference's grouping rule
+        # decay flag 2 = parameters whose .grad is always None in the reference (two-stream attn.cov_qkv.weight):
+        # nominally in the decay group, never stepped by torch's AdamW; the arena keeps them constant
         arena_decay = {n for n, _, _, _, d in model._layout if d}
         assert arena_decay == set(self.group_names["decay"]), "arena decay region != optim_factory decay group"
         self.model = model
