@@ -25,10 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE = 140.698        # student fwd + bwd + teacher fwd, algorithmic 2MNK
+GFLOP_BY_MODEL = {"beit_base_patch16_224": 140.698, "dist_beit_base_patch16_224": 281.396,
+                  "beit_large_patch16_224": 492.876, "dist_beit_large_patch16_224": 985.752}
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
 ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
-TRAFFIC_BYTES = None             # PMC-measured HBM bytes per launch (profiles/round1_pmc_fc1.txt); filled when collected
+TRAFFIC_BYTES = 418_000_000     # PMC: 2 x FETCH_SIZE (185 MB) + WRITE_SIZE (233 MB, mean of teacher/student launches); profiles/round1_pmc_hbm_v5.txt
 
 
 def synthetic_batch(B, seed, device):
@@ -67,6 +69,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
+    ap.add_argument("--model", default="beit_base_patch16_224",
+                    help="beit_base_patch16_224 (headline) | dist_beit_base_patch16_224 (--stochastic two-stream, BASELINE config 3) | "
+                         "beit_large_patch16_224 | dist_beit_large_patch16_224 (config 5 model)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,7 +89,8 @@ def main():
     from uncertainty_vit_amd.native import check, cur_stream, lib
 
     torch.manual_seed(0)           # identical initial weights on every rank (DDP broadcasts rank 0's)
-    model = create_model("beit_base_patch16_224", pretrained=False, drop_path_rate=0.25, drop_rate=0.0,
+    stochastic = a.model.startswith("dist_")
+    model = create_model(a.model, pretrained=False, drop_path_rate=0.25, drop_rate=0.0,
                          use_shared_rel_pos_bias=True, use_abs_pos_emb=False, init_values=1e-4, attn_drop_rate=0.05,
                          gp_layer=False, gumbel_softmax=False, sinkformer=False, h_sto_trans=False).to(dev)
     model.train()
@@ -109,7 +115,9 @@ def main():
         L.uvit_set_gemm_variant(int(os.environ["UVIT_GEMM_VARIANT"]))
 
     def step(i):
-        hp = make_step_params(list(range(6, 12)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, 0, i)
+        depth = model.depth
+        hp = make_step_params(list(range(depth // 2, depth)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, 0, i,
+                              lambda_pretraining=1e-5)
         hp.lr = 2e-5       # warm-up-sized lr: random-init weights and fixed synthetic data, 2e-3 is the post-warm-up peak
         native_step(engine, reducer, x, mask, hp)
         opt.step_count += 1
@@ -163,10 +171,11 @@ def main():
             "metric": "pretrain images/sec (ViT-B/16 224, bs=128/GPU)", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"beit_base_patch16_224 data2vec pretrain step, bs={a.batch}/GPU, 224x224 synthetic, "
-                                   "target_layers=[6..11], attn_drop 0.05, drop_path 0.25, clip 3.0, AdamW, EMA 0.9998",
+            "config": {"workload": f"{a.model} data2vec pretrain step{' (--stochastic: two-stream + Wasserstein loss)' if stochastic else ''}, "
+                                   f"bs={a.batch}/GPU, 224x224 synthetic, target_layers=upper half, attn_drop 0.05, drop_path 0.25, clip 3.0, "
+                                   "AdamW, EMA 0.9998",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "step_mfma_frac": round(value / world * GFLOP_PER_IMAGE * 1e9 / PEAK_BF16, 4),
+                       "model": a.model, "step_mfma_frac": round(value / world * GFLOP_BY_MODEL.get(a.model, GFLOP_PER_IMAGE) * 1e9 / PEAK_BF16, 4),
                        "final_loss": round(float(stats[0]), 5)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

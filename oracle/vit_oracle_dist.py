@@ -186,3 +186,21 @@ def train_step(params, ema, m, v, cfg, hp: vo.StepHParams, samples, mask, step, 
         vo.adamw_step(params, grads, m, v, step, hp)
         vo.ema_update(ema, params, hp.ema_decay)
     return vo.StepResult(float(loss.detach()), float(gnorm), out.detach(), targets, raw), float(loss_w.detach()), cov_out.detach(), cov_targets
+
+
+def drop_path_scales(seed: int, step: int, cfg: vo.VitConfig, B: int):
+    """path[k][layer] (B,) multipliers for the four draws of each block (k = 0 mean attn, 1 mean mlp, 2 cov attn,
+    3 cov mlp); mirrors `droppath_kernel` with nbr = 4 in csrc/elementwise.hip."""
+    import numpy as np
+    rates = cfg.drop_path_rates()
+    path = [[None] * cfg.depth for _ in range(4)]
+    with np.errstate(over="ignore"):
+        for i, r in enumerate(rates):
+            if r <= 0:
+                continue
+            for k in range(4):
+                key = vo._mix32(np.uint32(seed) ^ (np.uint32(step * 4 * cfg.depth + 4 * i + k + 1) * np.uint32(0x9E3779B9)))
+                rnd = vo._mix32(np.arange(B, dtype=np.uint32) ^ key)
+                thr = np.uint32(min(int(r * 4294967296.0), 0xFFFFFFFF))
+                path[k][i] = torch.from_numpy((rnd >= thr).astype(np.float32) / np.float32(1.0 - r))
+    return path

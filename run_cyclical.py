@@ -151,6 +151,8 @@ def get_model(args):
         # (the base model returns no (mean, cov) pairs).  The only self-consistent reading is the
         # two-stream architecture registered as dist_beit_base_patch16_224 (modeling_cyclical.py:304-323).
         name = "dist_beit_base_patch16_224"
+    if args.stochastic and name == "beit_large_patch16_224":
+        name = "dist_beit_large_patch16_224"
     print(f"Creating model: {name}")
     return create_model(name, pretrained=False, drop_path_rate=args.drop_path, drop_rate=args.drop,
                         use_shared_rel_pos_bias=args.rel_pos_bias, use_abs_pos_emb=args.abs_pos_emb,

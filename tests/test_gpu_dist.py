@@ -154,3 +154,44 @@ def test_two_stream_train_steps_vs_golden(golden_dir):
         check_entry(fx, "post/" + n, sd[n], 0, steps * 2 * 2e-3 + 1e-4, what="post ")
     for n in entries(fx, "ema"):
         check_entry(fx, "ema/" + n, esd[n], 0, steps * 2 * 2e-3 * 2e-4 + 1e-5, what="ema ")
+
+
+def test_two_stream_dropout_step_with_replayed_masks():
+    """attn_drop 0.1 + drop_path 0.3 on the two-stream model: the oracle replays the kernels' counter-based masks
+    (four independent drop-path draws per block, modeling_finetune_dist.py:51-55)."""
+    from uncertainty_vit_amd import engine_for_cyclical as eng, optim_factory, utils
+    from uncertainty_vit_amd.modeling_cyclical import DistVisionTransformerForCyclicalTraining
+    from oracle.closed_form import exact_masks
+    cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=3, num_heads=2, init_values=0.1, drop_path_rate=0.3, attn_drop_rate=0.1)
+    model = DistVisionTransformerForCyclicalTraining(
+        img_size=48, patch_size=16, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.1, use_shared_rel_pos_bias=True, use_abs_pos_emb=False,
+        drop_path_rate=0.3, attn_drop_rate=0.1)
+    sd = closed_form_state(vd.param_shapes(cfg), gamma=0.1)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
+    ema = utils.ModelEmaV2(model, decay=0.9998)
+    opt = optim_factory.create_optimizer(A(), model)
+    B = 6
+    x = closed_form_images("ddrop", B, 48)
+    mask = exact_masks(B, 9, 4, 91)
+    torch.manual_seed(4321)
+    st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, [1, 2], [((x.cuda(), mask.cuda()), torch.zeros(1))], opt,
+                             torch.device("cuda"), 0, utils.NativeScalerWithGradNormCount(), max_norm=3.0, l1_beta=2.0, start_steps=5,
+                             layer_results="end", loss_scale=-1, target_layer_norm_last=True, post_target_layer_norm=True,
+                             stochastic=True, lambda_pretraining=1e-2)
+    seed, it = torch.initial_seed() & 0xFFFFFFFF, 5
+    aseed = int(vo._mix32(np.uint32(seed) ^ np.uint32((it * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF)))
+    drop = vd.DistDropState(path=vd.drop_path_scales(seed, it, cfg, B),
+                            attn=[vo.attn_keep_mask(aseed, l, B, 2, 10, 0.1) for l in range(3)])
+    p = {k: v.clone() for k, v in sd.items()}
+    e = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    ref, _, _, _ = vd.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=(1, 2)), x, mask, 1, lam=1e-2, drop=drop)
+    assert st["loss"] == pytest.approx(ref.loss, rel=5e-3)
+    assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)
+    assert any(t is not None and (t == 0).any() for row in drop.path for t in row)

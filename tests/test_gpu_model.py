@@ -150,3 +150,24 @@ def test_dropout_step_matches_oracle_with_replayed_masks():
     assert st["loss"] == pytest.approx(ref.loss, rel=5e-3)
     assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)
     assert any(t is not None and (t == 0).any() for t in p1 + p2), "test should exercise a dropped path"
+
+
+def test_vit_large_step_vs_oracle():
+    """beit_large_patch16_224 (embed 1024, depth 24, heads 16; BASELINE config 5's architecture), B=1: one full step."""
+    cfg = vo.VitConfig(embed_dim=1024, depth=24, num_heads=16, init_values=0.1)
+    model, sd = native_model(cfg)
+    ema, opt = native_trainer(model)
+    x = closed_form_images("vitl-step", 1, 224)
+    mask = exact_masks(1, 196, 120, 23)
+    st = native_steps(model, ema, opt, [(x.cuda(), mask.cuda())], list(range(12, 24)))[0]
+    p = {k: v.clone() for k, v in sd.items()}
+    e = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    ref = vo.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=tuple(range(12, 24))), x, mask, 1)
+    assert st["loss"] == pytest.approx(ref.loss, rel=1e-2)
+    assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=5e-2)
+    grads = {n: q.grad for n, q in model.named_parameters()}
+    for n in ["blocks.0.attn.qkv.weight", "blocks.23.mlp.fc2.weight", "blocks.11.gamma_2", "lm_head.weight"]:
+        g, r = grads[n].float().cpu(), ref.grads[n]
+        assert (g - r).abs().max().item() <= 8e-2 * r.abs().max().item() + 1e-9, n

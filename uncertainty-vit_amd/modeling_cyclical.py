@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import native
 from .native import Buffers, Config, LayoutEntry, check, cur_stream, lib, ptr
 
-__all__ = ["beit_base_patch16_224", "dist_beit_base_patch16_224", "beit_large_patch16_224", "create_model", "register_model",
+__all__ = ["beit_base_patch16_224", "dist_beit_base_patch16_224", "beit_large_patch16_224", "dist_beit_large_patch16_224", "create_model", "register_model",
            "VisionTransformerForCyclicalTraining", "DistVisionTransformerForCyclicalTraining"]
 
 
@@ -447,6 +447,13 @@ def beit_base_patch16_224(pretrained=False, **kwargs):
 def dist_beit_base_patch16_224(pretrained=False, **kwargs):
     """modeling_cyclical.py:304-323: the model that returns (mean, cov) pairs, i.e. what `--stochastic` needs."""
     return _build(pretrained, kwargs, cls=DistVisionTransformerForCyclicalTraining, embed_dim=768, depth=12, num_heads=12)
+
+
+@register_model
+def dist_beit_large_patch16_224(pretrained=False, **kwargs):
+    """No reference entry point exists; defined by analogy for BASELINE config 5
+    (`beit_large_patch16_224 --stochastic`): embed 1024, depth 24, heads 16, two streams."""
+    return _build(pretrained, kwargs, cls=DistVisionTransformerForCyclicalTraining, embed_dim=1024, depth=24, num_heads=16)
 
 
 @register_model
