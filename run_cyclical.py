@@ -74,6 +74,8 @@ def get_args(argv=None):
     a("--data_path", default="/datasets01/imagenet_full_size/061417/", type=str)
     a("--data_set", default="IMNET", choices=["CIFAR100", "CIFAR10", "IMNET", "image_folder", "tiny_IMNET", "SYNTHETIC"], type=str)
     a("--synthetic_len", default=1024, type=int, help="images per epoch of the SYNTHETIC data set (new flag)")
+    a("--synthetic_masks", default="uniform", choices=["uniform", "block"],
+      help="SYNTHETIC masks: exactly num_mask_patches uniformly (default) or the block-wise generator (<= num_mask_patches) (new flag)")
     a("--imagenet_default_mean_and_std", default=False, action="store_true")
     a("--output_dir", default="")
     a("--log_dir", default=None)
@@ -129,8 +131,9 @@ class SyntheticPretrainSet(torch.utils.data.Dataset):
     """((image (3,S,S) f32 ~ N(0,1), mask (g,g) int64 with exactly n ones), 0) -- the loader contract of
     datasets.py:110-118 / engine_for_cyclical.py:45,58."""
 
-    def __init__(self, n, size, window, num_mask, seed):
+    def __init__(self, n, size, window, num_mask, seed, block=None):
         self.n, self.size, self.window, self.num_mask, self.seed = n, size, window, num_mask, seed
+        self.block = block          # (min_patches_per_block, max_patches_per_block) -> block-wise masks
 
     def __len__(self):
         return self.n
@@ -138,6 +141,11 @@ class SyntheticPretrainSet(torch.utils.data.Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1_000_003 + i)
         img = torch.randn(3, self.size, self.size, generator=g)
+        if self.block is not None:
+            from uncertainty_vit_amd.masking_generator import MaskingGenerator
+            gen = MaskingGenerator(tuple(self.window), self.num_mask, min_num_patches=self.block[0], max_num_patches=self.block[1],
+                                   seed=self.seed * 1_000_003 + i)
+            return (img, torch.from_numpy(gen())), 0
         P = self.window[0] * self.window[1]
         m = torch.zeros(P, dtype=torch.int64)
         m[torch.randperm(P, generator=g)[: self.num_mask]] = 1
@@ -179,7 +187,8 @@ def main(args):
     if args.data_set != "SYNTHETIC":
         raise NotImplementedError("only --data_set SYNTHETIC is available here: the image pipelines of datasets.py are out of scope")
 
-    dataset_train = SyntheticPretrainSet(args.synthetic_len, args.input_size, args.window_size, args.num_mask_patches, args.seed)
+    block = (args.min_mask_patches_per_block, args.max_mask_patches_per_block) if args.synthetic_masks == "block" else None
+    dataset_train = SyntheticPretrainSet(args.synthetic_len, args.input_size, args.window_size, args.num_mask_patches, args.seed, block)
     num_tasks, global_rank = utils.get_world_size(), utils.get_rank()
     num_training_steps_per_epoch = len(dataset_train) // args.batch_size // num_tasks
     sampler_train = torch.utils.data.DistributedSampler(dataset_train, num_replicas=num_tasks, rank=global_rank, shuffle=True)

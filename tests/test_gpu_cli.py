@@ -1,0 +1,39 @@
+"""End-to-end: the reference's command line (README.md:27-61 recipe, reduced) through run_cyclical.main on the GPU --
+synthetic images, block-wise masks, device prefetcher, cosine schedules, checkpoint + auto-resume."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+def _argv(out, epochs, extra=()):
+    return ["--model", "beit_base_patch16_224", "--data_set", "SYNTHETIC", "--synthetic_len", "32", "--batch_size", "8",
+            "--epochs", str(epochs), "--warmup_epochs", "0", "--lr", "5e-4", "--target_layers", "[8,9,10,11]",
+            "--num_mask_patches", "75", "--synthetic_masks", "block", "--num_workers", "0", "--output_dir", str(out),
+            "--clip_grad", "3.0", "--ema_decay", "0.999", "--drop_path", "0.1", *extra]
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_cli_trains_checkpoints_and_resumes(tmp_path, stochastic):
+    import run_cyclical
+    extra = ("--stochastic",) if stochastic else ()
+    run_cyclical.main(run_cyclical.get_args(_argv(tmp_path, 2, extra)))
+    log = [json.loads(l) for l in open(tmp_path / "log.txt")]
+    assert [l["epoch"] for l in log] == [0, 1]
+    assert all(0 < l["train_loss"] < 10 and l["train_grad_norm"] > 0 for l in log)
+    assert (tmp_path / "checkpoint-1.pth").exists()
+    ck = torch.load(tmp_path / "checkpoint-1.pth", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and "model_ema" in ck and "optimizer" in ck
+
+    # a second invocation with more epochs resumes after the newest checkpoint (utils.py:491-521)
+    args = run_cyclical.get_args(_argv(tmp_path, 3, extra))
+    run_cyclical.main(args)
+    assert args.start_epoch == 2
+    log = [json.loads(l) for l in open(tmp_path / "log.txt")]
+    assert [l["epoch"] for l in log] == [0, 1, 2] and 0 < log[2]["train_loss"] < 10

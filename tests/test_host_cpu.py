@@ -131,7 +131,7 @@ def test_cli_flags_and_defaults_match_reference(native, golden_dir):
     import run_cyclical
     ref = json.load(open(os.path.join(golden_dir, "cli_defaults.json")))
     mine = vars(run_cyclical.get_args([]))
-    assert mine.pop("synthetic_len") == 1024                      # the only new flag
+    assert mine.pop("synthetic_len") == 1024 and mine.pop("synthetic_masks") == "uniform"     # the only new flags
     assert mine == ref
     a = run_cyclical.get_args("--model beit_base_patch16_224 --stochastic --target_layers [6,7,8,9,10,11] --data_set SYNTHETIC".split())
     assert a.stochastic and a.model == "beit_base_patch16_224" and a.data_set == "SYNTHETIC"
@@ -211,3 +211,27 @@ def test_data_parallel_reducer_gloo_world2(native, tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-2000:]
         assert "ok" in o
+
+
+def test_blockwise_mask_generator_matches_reference(golden_dir):
+    """Bit-exact against masks drawn from the reference generator under the same random stream."""
+    from uncertainty_vit_amd.masking_generator import MaskingGenerator
+    fx = np.load(os.path.join(golden_dir, "masks.npz"))
+    cfgs = {"a": (14, 120, 16, None), "b": (14, 75, 16, None), "c": (14, 120, 4, 40), "d": (7, 20, 4, None)}
+    for name, (size, n, mn, mx) in cfgs.items():
+        for seed in (0, 1, 2):
+            g = MaskingGenerator(size, n, min_num_patches=mn, max_num_patches=mx, seed=1000 * seed + 7)
+            got = np.stack([g() for _ in range(4)])
+            assert got.dtype == np.int64 and np.array_equal(got, fx[f"{name}{seed}"]), (name, seed)
+            assert (got.sum(axis=(1, 2)) <= n).all() and got.max() <= 1        # at most n ones (SURVEY 8d)
+
+
+def test_device_prefetcher_passes_batches_through_in_order():
+    from uncertainty_vit_amd.engine_for_cyclical import DevicePrefetcher
+    batches = [((torch.full((2, 3, 4, 4), float(i), dtype=torch.float64), torch.ones(2, 2, 2, dtype=torch.bool)), i) for i in range(5)]
+    pf = DevicePrefetcher(batches, "cpu")
+    assert len(pf) == 5
+    got = list(pf)
+    assert [lbl for _, lbl in got] == list(range(5))
+    assert all(s.dtype == torch.float32 and float(s[0, 0, 0, 0]) == i for i, ((s, _), _) in enumerate(got))
+    assert list(DevicePrefetcher([], "cpu")) == []

@@ -235,6 +235,23 @@ def gen_schedules():
     print("wrote schedules")
 
 
+def gen_masks():
+    """Reference MaskingGenerator (masking_generator.py:29-92) under seeded global `random`; np.int no longer
+    exists in NumPy >= 1.24, so the harness restores the alias for the call."""
+    import random
+    import masking_generator as mg
+    if not hasattr(np, "int"):
+        np.int = int
+    out = {}
+    for name, (size, n, mn, mx) in {"a": (14, 120, 16, None), "b": (14, 75, 16, None), "c": (14, 120, 4, 40), "d": (7, 20, 4, None)}.items():
+        for seed in (0, 1, 2):
+            random.seed(1000 * seed + 7)
+            g = mg.MaskingGenerator(size, n, min_num_patches=mn, max_num_patches=mx)
+            out[f"{name}{seed}"] = np.stack([np.asarray(g(), dtype=np.int64) for _ in range(4)])
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
+    print("wrote masks", {k: int(v.sum()) for k, v in list(out.items())[:4]})
+
+
 def gen_cli_defaults():
     """Flag names / defaults of the reference CLI: exec the get_args() definition of run_cyclical.py:36-284
     (the module itself cannot be imported: datasets.py needs the missing cifar_semi)."""
@@ -272,6 +289,8 @@ def main():
         gen_vitb_spot(mc)
     if a.only in (None, "sched"):
         gen_schedules()
+    if a.only in (None, "masks"):
+        gen_masks()
     if a.only in (None, "cli"):
         gen_cli_defaults()
 

@@ -72,6 +72,47 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm)
 
 
+class DevicePrefetcher:
+    """Keeps one batch ahead of the step in HBM: the host->device copy of batch i+1 runs on a side HIP stream (from
+    pinned memory when the loader pins) while step i computes.  The reference copies inside the step loop on the
+    compute stream (engine_for_cyclical.py:58-59); the tensors handed out are the same.  CPU devices pass through."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _upload(self, item):
+        (samples, mask), label = item
+        if not self.on_gpu:
+            return (samples.to(self.device).float().contiguous(), mask.to(self.device)), label
+        with torch.cuda.stream(self.stream):
+            samples = samples.to(self.device, non_blocking=True).float().contiguous()
+            mask = mask.to(self.device, non_blocking=True)
+        return (samples, mask), label
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            ahead = self._upload(next(it))
+        except StopIteration:
+            return
+        while ahead is not None:
+            cur = ahead
+            if self.on_gpu:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+                for t in cur[0]:
+                    t.record_stream(torch.cuda.current_stream(self.device))
+            try:
+                ahead = self._upload(next(it))
+            except StopIteration:
+                ahead = None
+            yield cur
+
+
 def native_step(engine, reducer, samples, mask, hp):
     """One training iteration on the current stream; returns nothing (stats stay on the device)."""
     L, h, s = lib(), engine.h, cur_stream()
@@ -149,7 +190,7 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     seed = torch.initial_seed()
 
     cur_decay = decay
-    for step, (batch, _) in enumerate(metric_logger.log_every(data_loader, print_freq, header)):
+    for step, (batch, _) in enumerate(metric_logger.log_every(DevicePrefetcher(data_loader, device), print_freq, header)):
         it = start_steps + step  # global training iteration
         # per-step lr / weight-decay (engine_for_cyclical.py:47-53)
         if lr_schedule_values is not None or wd_schedule_values is not None:
@@ -162,8 +203,6 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
             cur_decay = decay_init + it * (decay - decay_init) / ema_start_at
 
         samples, bool_masked_pos = batch
-        samples = samples.to(device, non_blocking=True).float().contiguous()
-        bool_masked_pos = bool_masked_pos.to(device, non_blocking=True)
         if mask_dropout_prob > 0:
             keep = torch.bernoulli(torch.full_like(bool_masked_pos, 1 - mask_dropout_prob, dtype=samples.dtype))
             bool_masked_pos = torch.logical_and(keep, bool_masked_pos)
