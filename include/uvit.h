@@ -135,8 +135,8 @@ int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream str
 /* all of the above on one stream (single-GPU fast path) */
 int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
                     uvit_stream stream);
-/* Tuning / test hook for large NT GEMM shapes: 3 = auto by N (default), 2 = 128x256 tile with two workgroups
- * per CU, 1 = 256x256 with one workgroup per CU, 0 = 128x128 generic kernel. Process-wide. */
+/* Tuning / test hook for large NT GEMM shapes: 3 = auto by shape (default), 1 = 256x256 tile, staggered wave
+ * groups, one workgroup per CU, 0 = 128x128 generic kernel; other values are refused. Process-wide. */
 int uvit_set_gemm_variant(int v);
 /* Tuning hook: number of workgroups the wgrad GEMM's token split aims for (default 512). Process-wide. */
 int uvit_set_tn_split_target(int wgs);

@@ -62,21 +62,34 @@ def time_tn(M, N, K, iters=20):
 if __name__ == "__main__":
     M = 25216
     names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu"}
-    print("== NT: step shapes, variants 0 (128x128) / 1 (256x256) / 2 (128x256 x2 per CU) ==")
+    print("== NT: step shapes, variants 0 (128x128, 2 WG/CU) / 1 (256x256 staggered, 1 WG/CU) ==")
     for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
         row = []
-        for v in (0, 1, 2):
+        for v in (0, 1):
             L.uvit_set_gemm_variant(v)
             us, tf = time_nt(mode, M, N, K)
             row.append(f"v{v}: {us:7.1f} us {tf:6.1f} TF/s")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
     L.uvit_set_gemm_variant(3)
-    print("== NT: square references (variant 1) ==")
-    L.uvit_set_gemm_variant(1)
+    print("== NT: square references ==")
     for n in (4096, 8192):
-        us, tf = time_nt(0, n, n, n, iters=5)
-        print(f"{n}^3: {us:8.1f} us  {tf:7.1f} TF/s")
+        row = []
+        for v in (0, 1):
+            L.uvit_set_gemm_variant(v)
+            us, tf = time_nt(0, n, n, n, iters=5)
+            row.append(f"v{v}: {us:8.1f} us {tf:7.1f} TF/s")
+        print(f"{n}^3: " + " | ".join(row))
+    print("== NT: K sweep at M=25216 N=3072 ==")
+    for K in (128, 256, 768, 1536, 3072):
+        row = []
+        for v in (0, 1):
+            L.uvit_set_gemm_variant(v)
+            us, tf = time_nt(0, M, 3072, K)
+            row.append(f"v{v}: {us:7.1f} us {tf:6.1f} TF/s")
+        print(f"K={K:5d}: " + " | ".join(row))
     L.uvit_set_gemm_variant(3)
+    if "--tn" not in sys.argv:
+        sys.exit(0)
     print("== TN (wgrad), split target sweep ==")
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         row = []

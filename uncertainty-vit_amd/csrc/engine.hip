@@ -328,7 +328,7 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     delete e;
 }
 
-extern "C" int uvit_set_gemm_variant(int v) { if (v < 0 || v > 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
+extern "C" int uvit_set_gemm_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
 
 extern "C" int uvit_set_tn_split_target(int wgs) { uvit_gemm_set_tn_target(wgs); return UVIT_OK; }
 

@@ -70,53 +70,172 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     return 0.5f * (1.0f + e) + x * 0.39894228040143268f * gs;
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged epilogue.  The MFMA result layout gives a lane 4 consecutive columns of one row, i.e. 8-byte
+// bf16 stores in 32..64-byte row segments: the store path, not HBM, then sets the epilogue time.  Instead a
+// wave re-lays every 16-row x 64-column block of its accumulators through a private LDS slot (no barrier:
+// one wave's LDS operations execute in order) and touches global memory with 16 B per lane, 128 or 256
+// contiguous bytes per row:
+//   bf16-staged (BF16, QKV, QKV_ELU, GELU): values are finished (bias, ELU) and rounded before staging;
+//       slot = [16 rows][128 B], 16-B chunk c of row r at c ^ (r & 7), 8-B halves swapped for rows >= 8;
+//       read-back lane -> row 8i + lane/8, columns 8 (lane % 8) .. +7.
+//   fp32-staged (RESID, F32, PATCH: 4 columns per lane; DGELU: 8 columns per lane): raw accumulators;
+//       slot = [16 rows][256 B], chunk c of row r at c ^ r.
+// Both images are bank-conflict free for the ds_write / ds_read_b128 lane groups of gfx950.
+// ------------------------------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ void epilogue4(const GemmEpi& e, int m, int n, const ColVals& cv, f32x4 acc) {
-    const size_t o = (size_t)m * e.ldo + n;
-    if constexpr (MODE == EPI_BF16 || MODE == EPI_QKV) {
-        bf16x4 v = {f2bf(acc[0] + cv.b.x), f2bf(acc[1] + cv.b.y), f2bf(acc[2] + cv.b.z), f2bf(acc[3] + cv.b.w)};
-        *(bf16x4*)((bf16*)e.out + o) = v;
-    } else if constexpr (MODE == EPI_QKV_ELU) {
-        // cov_qkv = ELU(x) + 1  (= x + 1 for x > 0, exp(x) otherwise)
-        const float x0 = acc[0] + cv.b.x, x1 = acc[1] + cv.b.y, x2 = acc[2] + cv.b.z, x3 = acc[3] + cv.b.w;
-        bf16x4 v = {f2bf(x0 > 0.f ? x0 + 1.f : __expf(x0)), f2bf(x1 > 0.f ? x1 + 1.f : __expf(x1)),
-                    f2bf(x2 > 0.f ? x2 + 1.f : __expf(x2)), f2bf(x3 > 0.f ? x3 + 1.f : __expf(x3))};
-        *(bf16x4*)((bf16*)e.out + o) = v;
-    } else if constexpr (MODE == EPI_F32) {
-        *(float4*)((float*)e.out + o) = make_float4(acc[0] + cv.b.x, acc[1] + cv.b.y, acc[2] + cv.b.z, acc[3] + cv.b.w);
-    } else if constexpr (MODE == EPI_GELU) {
-        // pre-activation is kept in bf16 for backward; GELU is evaluated on the rounded value so
-        // forward and backward see the same h
-        bf16x4 hv = {f2bf(acc[0] + cv.b.x), f2bf(acc[1] + cv.b.y), f2bf(acc[2] + cv.b.z), f2bf(acc[3] + cv.b.w)};
-        if (e.out2) *(bf16x4*)((bf16*)e.out2 + o) = hv;
-        bf16x4 av = {f2bf(gelu_fast(bf2f(hv[0]))), f2bf(gelu_fast(bf2f(hv[1]))), f2bf(gelu_fast(bf2f(hv[2]))), f2bf(gelu_fast(bf2f(hv[3])))};
-        *(bf16x4*)((bf16*)e.out + o) = av;
-    } else if constexpr (MODE == EPI_RESID) {
-        // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
-        const float4 r = *(const float4*)(e.resid + o);
-        const float dp = e.rowscale ? e.rowscale[m / e.tokens] : 1.0f;
-        const float y0 = acc[0] + cv.b.x, y1 = acc[1] + cv.b.y, y2 = acc[2] + cv.b.z, y3 = acc[3] + cv.b.w;
-        if (e.out2) {
-            bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
-            *(bf16x4*)((bf16*)e.out2 + o) = yv;
+__device__ __forceinline__ constexpr bool stage_f32() {
+    return MODE == EPI_RESID || MODE == EPI_F32 || MODE == EPI_PATCH || MODE == EPI_DGELU;
+}
+#define EPI_SLOT_BF16 2048
+#define EPI_SLOT_F32 4096
+#define EPI_WAVE_BYTES 16384       // 8 bf16 blocks or 4 fp32 blocks in flight per wave
+
+template <int MODE>
+struct EpiCols {
+    float4 pre[4];   // bf16-staged: bias at the MFMA-layout columns ct*16 + 4g .. +3
+    float4 b, g;     // fp32-staged, 4 columns per lane: bias, and gamma (RESID) / mask token (PATCH), at the read-back columns
+};
+
+template <int MODE>
+__device__ __forceinline__ EpiCols<MODE> epi_cols(const GemmEpi& e, int nb, int lane, int N) {
+    EpiCols<MODE> c;
+    c.b = make_float4(0.f, 0.f, 0.f, 0.f);
+    c.g = c.b;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) c.pre[ct] = c.b;
+    if constexpr (!stage_f32<MODE>()) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int n = nb + ct * 16 + 4 * (lane >> 4);
+            c.pre[ct] = load_cols<MODE>(e, n < N ? n : 0, N).b;
         }
-        *(float4*)((float*)e.out + o) = make_float4(r.x + dp * cv.g.x * y0, r.y + dp * cv.g.y * y1,
-                                                    r.z + dp * cv.g.z * y2, r.w + dp * cv.g.w * y3);
-    } else if constexpr (MODE == EPI_PATCH) {
-        // row m = b*P + p of the patch GEMM lands in token row b*(P+1) + 1 + p; masked patches take
-        // the mask token (modeling_cyclical.py:179-182)
-        const int b = m / e.patches, p = m - b * e.patches;
-        const size_t orow = (size_t)(b * (e.patches + 1) + 1 + p) * e.ldo + n;
-        const bool masked = e.mask && e.mask[m] != 0;
-        const float4 v = masked ? cv.g : make_float4(acc[0] + cv.b.x, acc[1] + cv.b.y, acc[2] + cv.b.z, acc[3] + cv.b.w);
-        *(float4*)((float*)e.out + orow) = v;
-    } else if constexpr (MODE == EPI_DGELU) {
-        const bf16x4 h = *(const bf16x4*)((const bf16*)e.aux + o);
-        bf16x4 v = {f2bf(acc[0] * gelu_grad_fast(bf2f(h[0]))), f2bf(acc[1] * gelu_grad_fast(bf2f(h[1]))),
-                    f2bf(acc[2] * gelu_grad_fast(bf2f(h[2]))), f2bf(acc[3] * gelu_grad_fast(bf2f(h[3])))};
-        *(bf16x4*)((bf16*)e.out + o) = v;
+    } else if constexpr (MODE != EPI_DGELU) {
+        const int n = nb + 4 * (lane & 15);
+        const ColVals v = load_cols<MODE>(e, n < N ? n : 0, N);
+        c.b = v.b; c.g = v.g;
+    }
+    return c;
+}
+
+// write one 16x64 block (a[ct] = columns ct*16 + 4g .. +3 of row li) into its slot
+template <int MODE>
+__device__ __forceinline__ void epi_stage(const EpiCols<MODE>& c, char* slot, int lane, const f32x4 a0, const f32x4 a1,
+                                          const f32x4 a2, const f32x4 a3) {
+    const int g = lane >> 4, li = lane & 15;
+    const f32x4 a[4] = {a0, a1, a2, a3};
+    if constexpr (!stage_f32<MODE>()) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float x0 = a[ct][0] + c.pre[ct].x, x1 = a[ct][1] + c.pre[ct].y, x2 = a[ct][2] + c.pre[ct].z, x3 = a[ct][3] + c.pre[ct].w;
+            if constexpr (MODE == EPI_QKV_ELU) {
+                // cov_qkv = ELU(x) + 1  (= x + 1 for x > 0, exp(x) otherwise)
+                x0 = x0 > 0.f ? x0 + 1.f : __expf(x0); x1 = x1 > 0.f ? x1 + 1.f : __expf(x1);
+                x2 = x2 > 0.f ? x2 + 1.f : __expf(x2); x3 = x3 > 0.f ? x3 + 1.f : __expf(x3);
+            }
+            const bf16x4 v = {f2bf(x0), f2bf(x1), f2bf(x2), f2bf(x3)};
+            const int chunk = (ct * 2 + (g >> 1)) ^ (li & 7);
+            const int half = (g & 1) ^ (li >> 3);
+            *(bf16x4*)(slot + li * 128 + chunk * 16 + half * 8) = v;
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            *(f32x4*)(slot + li * 256 + (((ct * 4 + g) ^ li) << 4)) = a[ct];
     }
 }
+
+__device__ __forceinline__ void epi_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// read one staged block back row-contiguously and finish it: block rows mb.., block columns nb..
+template <int MODE>
+__device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>& c, const char* slot, int lane,
+                                          int mb, int nb, int M, int N) {
+    if constexpr (!stage_f32<MODE>()) {
+        const int cc = lane & 7, n = nb + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * i + (lane >> 3), m = mb + row;
+            bf16x8 v = *(const bf16x8*)(slot + row * 128 + ((cc ^ (lane >> 3)) << 4));
+            if (i == 1) v = __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3);
+            if (m >= M || n >= N) continue;
+            const size_t o = (size_t)m * e.ldo + n;
+            if constexpr (MODE == EPI_GELU) {
+                // the pre-activation is kept in bf16 for backward; GELU is evaluated on the rounded value so
+                // forward and backward see the same h
+                if (e.out2) *(bf16x8*)((bf16*)e.out2 + o) = v;
+                bf16x8 av;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = f2bf(gelu_fast(bf2f(v[j])));
+                *(bf16x8*)((bf16*)e.out + o) = av;
+            } else {
+                *(bf16x8*)((bf16*)e.out + o) = v;
+            }
+        }
+    } else if constexpr (MODE == EPI_DGELU) {
+        const int cc = lane & 7, n = nb + cc * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 8 * i + (lane >> 3), m = mb + row;
+            const f32x4 lo = *(const f32x4*)(slot + row * 256 + (((2 * cc) ^ row) << 4));
+            const f32x4 hi = *(const f32x4*)(slot + row * 256 + (((2 * cc + 1) ^ row) << 4));
+            if (m >= M || n >= N) continue;
+            const size_t o = (size_t)m * e.ldo + n;
+            const bf16x8 h = *(const bf16x8*)((const bf16*)e.aux + o);
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = f2bf(lo[j] * gelu_grad_fast(bf2f(h[j])));
+                v[4 + j] = f2bf(hi[j] * gelu_grad_fast(bf2f(h[4 + j])));
+            }
+            *(bf16x8*)((bf16*)e.out + o) = v;
+        }
+    } else {
+        const int cc = lane & 15, n = nb + cc * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + (lane >> 4), m = mb + row;
+            const f32x4 a = *(const f32x4*)(slot + row * 256 + ((cc ^ row) << 4));
+            if (m >= M || n >= N) continue;
+            const float y0 = a[0] + c.b.x, y1 = a[1] + c.b.y, y2 = a[2] + c.b.z, y3 = a[3] + c.b.w;
+            if constexpr (MODE == EPI_F32) {
+                *(float4*)((float*)e.out + (size_t)m * e.ldo + n) = make_float4(y0, y1, y2, y3);
+            } else if constexpr (MODE == EPI_RESID) {
+                // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
+                const size_t o = (size_t)m * e.ldo + n;
+                const float4 r = *(const float4*)(e.resid + o);
+                const float dp = e.rowscale ? e.rowscale[m / e.tokens] : 1.0f;
+                if (e.out2) {
+                    const bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
+                    *(bf16x4*)((bf16*)e.out2 + o) = yv;
+                }
+                *(float4*)((float*)e.out + o) = make_float4(r.x + dp * c.g.x * y0, r.y + dp * c.g.y * y1,
+                                                            r.z + dp * c.g.z * y2, r.w + dp * c.g.w * y3);
+            } else {   // EPI_PATCH
+                // row m = b*P + p of the patch GEMM lands in token row b*(P+1) + 1 + p; masked patches take
+                // the mask token (modeling_cyclical.py:179-182)
+                const int b = m / e.patches, p_ = m - b * e.patches;
+                const size_t orow = (size_t)(b * (e.patches + 1) + 1 + p_) * e.ldo + n;
+                const bool masked = e.mask && e.mask[m] != 0;
+                *(float4*)((float*)e.out + orow) = masked ? c.g : make_float4(y0, y1, y2, y3);
+            }
+        }
+    }
+}
+
+// NB blocks of one wave: ACC(b, ct) names the accumulator of block b, column sub-tile ct; MB(b) its first row.
+#define EPI_RUN(MODE, NB, region, nb_, ACC, MB) do { \
+        const EpiCols<MODE> cols_ = epi_cols<MODE>(epi, (nb_), lane, N); \
+        constexpr int SLOT_ = stage_f32<MODE>() ? EPI_SLOT_F32 : EPI_SLOT_BF16; \
+        constexpr int GRP_ = EPI_WAVE_BYTES / SLOT_ < (NB) ? EPI_WAVE_BYTES / SLOT_ : (NB); \
+        _Pragma("unroll") for (int b0_ = 0; b0_ < (NB); b0_ += GRP_) { \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
+                epi_stage<MODE>(cols_, (region) + b_ * SLOT_, lane, ACC(b0_ + b_, 0), ACC(b0_ + b_, 1), ACC(b0_ + b_, 2), ACC(b0_ + b_, 3)); \
+            epi_sync(); \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
+                epi_flush<MODE>(epi, cols_, (region) + b_ * SLOT_, lane, MB(b0_ + b_), (nb_), M, N); \
+            epi_sync(); \
+        } } while (0)
 
 // ------------------------------------------------------------------------------------------
 // NT kernel
@@ -193,22 +312,12 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
         }
     }
     // D layout (swapped operands): lane col (li) = m_local, rows 4g+r = n_local
-    ColVals cv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + 4 * g;
-        cv[nt] = load_cols<MODE>(epi, n < N ? n : 0, N);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wr * 64 + mt * 16 + li;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wc * 64 + nt * 16 + 4 * g;
-            if (n < N) epilogue4<MODE>(epi, m, n, cv[nt], acc[mt][nt]);
-        }
-    }
+    __syncthreads();                                   // every wave is done reading the operand stages
+#define ACC0(b, ct) acc[b][ct]
+#define MB0(b) (m0 + wr * 64 + (b) * 16)
+    EPI_RUN(MODE, 4, smem + wave * EPI_WAVE_BYTES, n0 + wc * 64, ACC0, MB0);
+#undef ACC0
+#undef MB0
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,13 +328,9 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 // {wn*32.. in BL} u {wn*32.. in BH}, so each K-tile is consumed in 4 phases of 16 MFMAs
 // (one 64x32 quadrant each) that read
 //        p0: AL + BL      p1: BH      p2: AH      p3: -  (BL fragments stay in registers)
-// A half-tile slot is therefore free one phase after its single read, and the loader refills it
-// immediately with the half-tile of K-tile t+2 (t+1 for AH): every global_load_lds has >= 6
-// phases (~3000 cycles) of flight time and 5 half-tiles (80 KiB) are in flight per CU while the
-// MFMA pipe works -- prefetch depth comes from the consumption order, not from more LDS.
-// Ordering: RAW by a counted `s_waitcnt vmcnt(10)` (5 younger half-tiles x 2 loads per thread)
-// placed one phase before the read and followed by that phase's barrier; WAR by the
-// lgkmcnt(0) + barrier that closes the reading phase.  Never vmcnt(0) in the steady state.
+// A half-tile slot is read in exactly one phase per K-tile, so the loader can refill it soon after with
+// the half-tile of a later K-tile: prefetch depth comes from the consumption order, not from more LDS.
+// Never vmcnt(0) in the steady state.  The schedule itself is documented at the kernel below.
 // ------------------------------------------------------------------------------------------
 #define T_BM 256
 #define T_BN 256
@@ -237,17 +342,29 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 #define LDS_WAIT() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RAW_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+// ------------------------------------------------------------------------------------------
+// The two wave groups wm = 0 / wm = 1 (one wave of each per SIMD) run half a phase apart -- wm = 1
+// takes one extra barrier up front -- so while one group issues its 16 MFMAs the other does its
+// ds_reads, LDS-DMA issue and counted wait, and the MFMA pipe of every SIMD stays fed.
+// The stagger moves the hazards by one barrier, so the half-tile schedule differs from the lockstep kernel:
+//        phase:   p0            p1          p2          p3
+//        reads:   AL(t) BL(t)   BH(t)       AH(t)       -
+//        issues:  BH(t+1)       AH(t+1)     AL(t+2)     BL(t+2)
+//        waits:   BH(t)         AH(t)       -           AL(t+1) BL(t+1)
+// RAW: a half-tile is read one phase after the phase whose counted vmcnt (before that phase's first
+// barrier) retired it -- the trailing group's wait is then also behind a barrier the reader has passed.
+// WAR: every slot is refilled >= 2 phases after its last read (the trailing group's reads of phase p
+// complete before barrier 2p+2; the leading group issues phase p+2's DMA after barrier 2p+3).
+// 4 half-tiles (64 KiB) are in flight behind every wait: vmcnt(8), exact smaller counts in the K tail.
+// ------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(T_THREADS, 2)
 void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
-                       int lda, int ldw, GemmEpi epi) {
+                        int lda, int ldw, GemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = N / T_BN, tiles_m = (M + T_BM - 1) / T_BM;
-    // tile order: XCD-contiguous chunks (T1), inside them N-groups of <= 6 column tiles walked for every
-    // row tile: one group's W panels (6 x 384 KiB at K = 768) stay resident in the XCD's 4 MiB L2 beside
-    // the streaming A panels instead of the whole W being re-fetched every tile round (PMC: profiles/).
     int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
     int tn0 = 0;
@@ -257,30 +374,30 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
 
-    // ---- loader: half-tile = 16 wave-instructions of 8 rows; this wave issues instructions {wave, 8 + wave}
     const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;              // swizzle on the SOURCE side (LDS image stays lane-linear)
+    const int schunk = (lane & 7) ^ srow;
     const bf16* src[4][2];                             // [AL, AH, BL, BH][instruction]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int r = (j * 8 + wave) * 8 + srow;       // row inside the half-tile
+        const int r = (j * 8 + wave) * 8 + srow;
         int ra = m0 + r;        ra = ra < M ? ra : M - 1;
         int rb = m0 + 128 + r;  rb = rb < M ? rb : M - 1;
         src[0][j] = A + (size_t)ra * lda + schunk * 8;
         src[1][j] = A + (size_t)rb * lda + schunk * 8;
-        src[2][j] = W + (size_t)(n0 + r) * ldw + schunk * 8;
-        src[3][j] = W + (size_t)(n0 + 128 + r) * ldw + schunk * 8;
+        // a wave's 2 x 32 output columns are adjacent (BL row r <-> column 64 (r / 32) + r % 32, BH +32): full
+        // 128-B lines per row in the staged epilogue
+        const int cb = (r >> 5) * 64 + (r & 31);
+        src[2][j] = W + (size_t)(n0 + cb) * ldw + schunk * 8;
+        src[3][j] = W + (size_t)(n0 + cb + 32) * ldw + schunk * 8;
     }
     const int nk = K / BK;
-    auto issue = [&](int kind, int t) {                // half-tile `kind` of K-tile t -> buffer t&1
+    auto issue = [&](int kind, int t) {
         if (t < nk) {
             char* dst = smem + (t & 1) * (4 * HALF_BYTES) + kind * HALF_BYTES + wave * 1024;
             glds16(src[kind][0] + (size_t)t * BK, dst);
             glds16(src[kind][1] + (size_t)t * BK, dst + 8 * 1024);
         }
     };
-
-    // ---- fragment addressing: row*128 + ((chunk ^ (row&7)) << 4); (row & 7) == (li & 7) for every tile row
     const int sw0 = ((g) ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
     const int a_off = (wm * 64 + li) * 128, b_off = (wn * 32 + li) * 128;
 
@@ -293,7 +410,6 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     bf16x8 af[4][2], b0f[2][2], b1f[2][2];
 
 #define LOAD_A(half_base) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { \
@@ -309,189 +425,57 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
             acc[mq][nq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][kk], af[mt][kk], acc[mq][nq][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0); } while (0)
 
-    // ---- prologue: AL0 BL0 BH0 AH0 AL1 BL1 BH1 (AH1 is issued in phase 0 of tile 0)
+    // ---- prologue: AL0 BL0 BH0 AH0 AL1 BL1 (BH1, AH1 are issued in phases 0, 1 of tile 0)
     issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
-    issue(0, 1); issue(2, 1); issue(3, 1);
-    if (nk >= 2) VM_WAIT(10); else VM_WAIT(0);         // AL0, BL0 landed (5 younger half-tiles may fly)
+    issue(0, 1); issue(2, 1);
+    if (nk >= 2) VM_WAIT(8); else VM_WAIT(4);          // AL0, BL0 landed
     RAW_BARRIER();
+    if (wm == 1) RAW_BARRIER();                        // the stagger: wm = 1 runs one barrier behind
 
     for (int t = 0; t < nk; ++t) {
         const char* buf = smem + (t & 1) * (4 * HALF_BYTES);
-        const bool steady2 = t + 2 < nk;               // the load this phase would issue exists
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
         // ---- phase 0: quadrant (0,0) <- AL, BL
-        LOAD_A(buf);
         LOAD_B(b0f, buf + 2 * HALF_BYTES);
-        issue(1, t + 1);                               // AH(t+1): its slot was last read in phase 2 of tile t-1
-        if (t + 1 < nk) VM_WAIT(10); else VM_WAIT(0);  // BH(t) landed -> read next phase
+        LOAD_A(buf);
+        issue(3, t + 1);                               // BH(t+1): slot last read in phase 1 of tile t-1
+        if (has1) VM_WAIT(8); else VM_WAIT(2);         // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
         RAW_BARRIER();
         LDS_WAIT();
         MMA(0, 0, b0f);
         RAW_BARRIER();
         // ---- phase 1: quadrant (0,1) <- BH
         LOAD_B(b1f, buf + 3 * HALF_BYTES);
-        issue(0, t + 2);                               // AL(t+2): slot read in phase 0
-        if (steady2) VM_WAIT(10); else VM_WAIT(0);     // AH(t) landed
+        issue(1, t + 1);                               // AH(t+1): slot last read in phase 2 of tile t-1
+        if (has1) VM_WAIT(8); else VM_WAIT(0);         // AH(t) landed
         RAW_BARRIER();
         LDS_WAIT();
         MMA(0, 1, b1f);
         RAW_BARRIER();
         // ---- phase 2: quadrant (1,1) <- AH
         LOAD_A(buf + HALF_BYTES);
-        issue(2, t + 2);                               // BL(t+2): slot read in phase 0 (fragments live in registers)
+        issue(0, t + 2);                               // AL(t+2): slot last read in phase 0
         RAW_BARRIER();
         LDS_WAIT();
         MMA(1, 1, b1f);
         RAW_BARRIER();
         // ---- phase 3: quadrant (1,0), no LDS read
-        issue(3, t + 2);                               // BH(t+2): slot read in phase 1
-        if (steady2) VM_WAIT(10); else VM_WAIT(0);     // AL(t+1), BL(t+1) landed
+        issue(2, t + 2);                               // BL(t+2): slot last read in phase 0
+        if (has2) VM_WAIT(8); else if (has1) VM_WAIT(4);   // AL(t+1), BL(t+1) landed
         RAW_BARRIER();
         MMA(1, 0, b0f);
         RAW_BARRIER();
     }
+    if (wm == 0) RAW_BARRIER();                        // matches the trailing group's last barrier
 #undef LOAD_A
 #undef LOAD_B
 #undef MMA
 
-    // D layout (swapped operands): lane col (li) = m_local, rows 4g+r = n_local
-    ColVals cv[2][2];
-#pragma unroll
-    for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) cv[nq][nt] = load_cols<MODE>(epi, n0 + nq * 128 + wn * 32 + nt * 16 + 4 * g, N);
-#pragma unroll
-    for (int mq = 0; mq < 2; ++mq)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + mq * 128 + wm * 64 + mt * 16 + li;
-            if (m >= M) continue;
-#pragma unroll
-            for (int nq = 0; nq < 2; ++nq)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    epilogue4<MODE>(epi, m, n0 + nq * 128 + wn * 32 + nt * 16 + 4 * g, cv[nq][nt], acc[mq][nq][mt][nt]);
-        }
-}
-
-// ------------------------------------------------------------------------------------------
-// NT kernel, two workgroups per CU: 128x256 block tile, BK = 32, 4 waves (1 M x 4 N, 128x64 each),
-// 3-stage LDS ring of 24 KiB stages (72 KiB -> two resident workgroups per CU).  Loads run two K-tiles
-// ahead behind a counted vmcnt, one barrier per K-tile.  The two co-resident workgroups are
-// independent, so one's HBM-bound epilogue (and its tile-quantisation tail) overlaps the other's
-// MFMA loop -- which the one-workgroup-per-CU 256x256 kernel cannot do at K = 768.
-// LDS image: [rows][32 k] bf16 = 64-B rows, 16-B chunk c of row r stored at chunk c ^ (-(r>>2) & 3):
-// conflict-free for the ds_read_b128 lane groups (4 rows share a 256-B bank row).
-// ------------------------------------------------------------------------------------------
-#define P_BM 128
-#define P_BN 256
-#define P_BK 32
-#define P_THREADS 256
-#define P_STAGE_A (P_BM * P_BK * 2)                 // 8 KiB
-#define P_STAGE (P_STAGE_A + P_BN * P_BK * 2)       // 24 KiB
-#define P_LDS_BYTES (3 * P_STAGE)                   // 72 KiB
-
-template <int MODE>
-__global__ __launch_bounds__(P_THREADS, 2)
-void gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
-                     int lda, int ldw, GemmEpi epi) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = N / P_BN, tiles_m = (M + P_BM - 1) / P_BM;
-    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
-    int tn0 = 0;
-    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
-    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
-    const int m0 = tm * P_BM, n0 = tn * P_BN;
-    const int g = lane >> 4, li = lane & 15;
-
-    // loader: a wave-instruction covers 16 rows x 64 B.  A = 8 instructions (2 per wave), W = 16 (4 per wave)
-    const int srow = lane >> 2;
-    const int schunk = (lane & 3) ^ ((-(lane >> 4)) & 3);          // row>>2 & 3 == lane>>4 (instruction rows start at a multiple of 16)
-    // 32-bit element offsets from the (scalar) base pointers keep the loader at 6 VGPRs
-    uint32_t a_src[2], w_src[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int r = m0 + (j * 4 + wave) * 16 + srow; r = r < M ? r : M - 1;
-        a_src[j] = (uint32_t)r * (uint32_t)lda + schunk * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w_src[j] = (uint32_t)(n0 + (j * 4 + wave) * 16 + srow) * (uint32_t)ldw + schunk * 8;
-    const int nk = K / P_BK;
-    auto issue = [&](int t) {
-        if (t < nk) {
-            char* st = smem + (t % 3) * P_STAGE;
-            const uint32_t k0 = (uint32_t)t * P_BK;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(A + (a_src[j] + k0), st + (j * 4 + wave) * 1024);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(W + (w_src[j] + k0), st + P_STAGE_A + (j * 4 + wave) * 1024);
-        }
-    };
-
-    // fragment address inside a stage: row*64 + ((g ^ (-(row>>2) & 3)) << 4); tile rows = 16*mt + li
-    const int fsw = (g ^ ((-(li >> 2)) & 3)) << 4;
-    const int a_off = li * 64 + fsw;
-    const int b_off = P_STAGE_A + (wave * 64 + li) * 64 + fsw;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Software pipeline: fragments of K-tile t+1 are read from LDS (into the other register set) while the MFMAs
-    // of K-tile t run; the global loads of K-tile t+3 go into the stage whose fragments were consumed an iteration
-    // ago.  One barrier per K-tile: it publishes "K-tile t+2 has landed" and "stage (t+1)%3 has been read".
-    bf16x8 afA[8], wfA[4], afB[8], wfB[4];
-#define LOADF(af_, wf_, t_) do { const char* st_ = smem + ((t_) % 3) * P_STAGE; \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) wf_[nt] = *(const bf16x8*)(st_ + b_off + nt * 1024); \
-        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) af_[mt] = *(const bf16x8*)(st_ + a_off + mt * 1024); } while (0)
-#define MMA32(af_, wf_) do { __builtin_amdgcn_s_setprio(1); \
-        _Pragma("unroll") for (int mt = 0; mt < 8; ++mt) \
-        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) \
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_[nt], af_[mt], acc[mt][nt], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0); } while (0)
-#define STEP(afc, wfc, afn, wfn, t_) do { \
-        issue((t_) + 3);                                            /* stage t%3: consumed last iteration */ \
-        if ((t_) + 1 < nk) LOADF(afn, wfn, (t_) + 1);               /* K-tile t+1: published by the last barrier */ \
-        MMA32(afc, wfc); \
-        if ((t_) + 3 < nk) VM_WAIT(6); else VM_WAIT(0);             /* K-tile t+2 landed (t+3's 6 loads may fly) */ \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this wave is done reading stage (t+1)%3 */ \
-        RAW_BARRIER(); } while (0)
-
-    issue(0);
-    issue(1);
-    issue(2);
-    if (nk >= 3) VM_WAIT(12); else if (nk == 2) VM_WAIT(6); else VM_WAIT(0);    // K-tile 0 landed
-    RAW_BARRIER();
-    LOADF(afA, wfA, 0);
-    if (nk >= 3) VM_WAIT(6); else VM_WAIT(0);                                    // K-tile 1 landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    RAW_BARRIER();
-    // invariant at the top of STEP(t): fragments of t in registers, K-tile t+1 published, t+2 in flight, stage t%3 free
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-        STEP(afA, wfA, afB, wfB, t);
-        STEP(afB, wfB, afA, wfA, t + 1);
-    }
-    if (t < nk) STEP(afA, wfA, afB, wfB, t);
-#undef LOADF
-#undef MMA32
-#undef STEP
-
-    ColVals cv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) cv[nt] = load_cols<MODE>(epi, n0 + wave * 64 + nt * 16 + 4 * g, N);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + mt * 16 + li;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            epilogue4<MODE>(epi, m, n0 + wave * 64 + nt * 16 + 4 * g, cv[nt], acc[mt][nt]);
-    }
+#define ACC1(b, ct) acc[(b) >> 2][(ct) >> 1][(b) & 3][(ct) & 1]
+#define MB1(b) (m0 + ((b) >> 2) * 128 + wm * 64 + ((b) & 3) * 16)
+    EPI_RUN(MODE, 8, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
+#undef ACC1
+#undef MB1
 }
 
 // ------------------------------------------------------------------------------------------
@@ -637,7 +621,7 @@ static bool g_attr_done = false;
 static int g_variant = 3;
 static int g_tn_target = 512;     // MI355X sweep (tools/bench_gemm.py): 512 beats 256..1536 on all four wgrad shapes
 void uvit_gemm_set_tn_target(int wgs) { g_tn_target = wgs > 0 ? wgs : 512; }
-void uvit_gemm_set_variant(int v) { g_variant = v; }
+void uvit_gemm_set_variant(int v) { g_variant = (v == 0 || v == 1) ? v : 3; }
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
@@ -649,9 +633,6 @@ static void gemm_init_once() {
 #define ALLOW256(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES)
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU);
 #undef ALLOW256
-#define ALLOW2(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES)
-    ALLOW2(EPI_BF16); ALLOW2(EPI_QKV); ALLOW2(EPI_GELU); ALLOW2(EPI_RESID); ALLOW2(EPI_F32); ALLOW2(EPI_PATCH); ALLOW2(EPI_DGELU); ALLOW2(EPI_QKV_ELU);
-#undef ALLOW2
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     g_attr_done = true;
 }
@@ -661,20 +642,18 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
-    // variant: 0 = 128x128 (any shape), 1 = 256x256 one workgroup/CU, 2 = 128x256 two workgroups/CU,
-    // 3 = auto, from tools/bench_gemm.py on MI355X at M = 25216 (profiles/round1_gemm_variants.txt):
-    //   N <= 1024 (proj, fc2, every dgrad): 128x128, 1182 tiles keep both resident workgroups of all CUs busy;
-    //   N >= 3072 (fc1, its GELU' dgrad):   256x256, fewest operand bytes per FLOP beside a heavy epilogue;
-    //   between (qkv):                      128x256.
+    // variant: 0 = 128x128 (any shape, two workgroups per CU), 1 = 256x256 staggered (one per CU), 3 = auto from
+    // tools/bench_gemm.py on MI355X at M = 25216 (profiles/round1_gemm_variants_v2.txt):
+    //   N >= 2048 (qkv, fc1, fc1's GELU' dgrad): 256x256 -- 891..1188 tiles fill >= 87 % of their last round;
+    //   N = 768: 297 such tiles would leave 42 % of the second round idle -> 128x128 (1182 tiles), except the
+    //   K = 3072 residual epilogue (fc2), where the deeper pipeline still wins.
     const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0;
     int variant = shape_ok ? g_variant : 0;
-    if (variant == 3) variant = N <= 1024 ? 0 : (N >= 3072 ? 1 : 2);
-    const int grid = variant == 1 ? ((M + T_BM - 1) / T_BM) * (N / T_BN)
-                   : variant == 2 ? ((M + P_BM - 1) / P_BM) * (N / P_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (variant == 3) variant = (N >= 2048 || (mode == EPI_RESID && K >= 2048)) ? 1 : 0;
+    const int grid = variant == 1 ? ((M + T_BM - 1) / T_BM) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
 #define L(MODE) do { if (variant == 1) hipLaunchKernelGGL(gemm_nt256_kernel<MODE>, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
-        else if (variant == 2) hipLaunchKernelGGL(gemm_nt2_kernel<MODE>, dim3(grid), dim3(P_THREADS), P_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi); } while (0)
     switch (mode) {
         case EPI_BF16: L(EPI_BF16); break;

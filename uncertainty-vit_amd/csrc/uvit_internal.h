@@ -24,7 +24,7 @@ struct GemmEpi {
 // gemm.hip
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
                         const GemmEpi* epi, hipStream_t s);
-void uvit_gemm_set_variant(int v);   // 0: 128x128, 1: 256x256 (1 WG/CU), 2: 128x256 (2 WG/CU, default) for large shapes
+void uvit_gemm_set_variant(int v);   // 0: 128x128, 1: 256x256 staggered (1 WG/CU), 3: auto by shape
 void uvit_gemm_set_tn_target(int wgs);   // workgroups the wgrad split-K aims for
 // allow_split: partial sums are combined with fp32 atomics -> C must be zero (or hold a value to add to)
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
