@@ -138,6 +138,8 @@ int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, co
 /* Tuning / test hook for large NT GEMM shapes: 3 = auto by shape (default), 1 = 256x256 tile, staggered wave
  * groups, one workgroup per CU, 0 = 128x128 generic kernel; other values are refused. Process-wide. */
 int uvit_set_gemm_variant(int v);
+/* Tuning / test hook for the wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128. */
+int uvit_set_tn_variant(int v);
 /* Tuning hook: number of workgroups the wgrad GEMM's token split aims for (default 512). Process-wide. */
 int uvit_set_tn_split_target(int wgs);
 /* dual = 1 (default): teacher forward and the wgrad GEMMs run on an internal second HIP stream beside the
@@ -168,6 +170,18 @@ int uvit_op_gemm_nt(int mode, const void* A_bf16, const void* W_bf16, int M, int
 /* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64 */
 int uvit_op_gemm_tn(const void* Y_bf16, const void* X_bf16, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
                     uvit_stream stream);
+/* All weight gradients of one layer's Linears in one launch (256x256 tiles, token-chunked, fp32 atomics into C).
+ * Every problem: M % 64 == 0 and M >= 512, N % 256 == 0, K % 256 == 0; C (and the bias outputs) must hold zeros or a
+ * value to add to.  bias (nullable) receives the column sums of Y[:, 0:bias_end) -- the Linear's bias gradient,
+ * modeling_finetune.py:149-151 for the qkv split -- and bias2 (nullable) those of Y[:, bias2_begin:N); both bounds
+ * are multiples of 256.  Returns UVIT_ERR_SHAPE (nothing launched) when a problem does not qualify. */
+typedef struct uvit_wgrad_problem {
+    const void* Y_bf16; const void* X_bf16; float* C; float* bias; float* bias2;
+    int32_t bias_end, bias2_begin, M, N, K, ldy, ldx, ldc;
+} uvit_wgrad_problem;
+int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, uvit_stream stream);
+/* Tuning hook: token chunks per output tile in uvit_op_wgrad_group (0 = cost model, default). Process-wide. */
+int uvit_set_wgrad_group_chunks(int chunks);
 /* Attention core, modeling_finetune.py:152-185. qkv (B,N,3,H,64) bf16; biasP (H,NP,NP) f32 or NULL in the kernels'
  * private layout built by uvit_op_relpos_gather: bias * log2(e), -1e30 in padded key columns; lse is in log2 units */
 int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,

@@ -178,6 +178,79 @@ def test_gemm_tn_wgrad(L, M, N, K):
     close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M / 64), what="wgrad")
 
 
+@pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (1024, 768, 3072), (512, 256, 256), (576, 2304, 768)])
+def test_gemm_tn_wgrad_256_tile_kernel(L, M, N, K):
+    """The 256x256 staggered wgrad kernel: split reductions (fp32 atomics), the no-split store path (M = 512),
+    odd K-tile counts, and a race screen on a shape without atomics (bit-identical every launch)."""
+    ok(L.uvit_set_tn_variant(1))
+    try:
+        y, x = bf(rnd(M, N, scale=0.1, seed=20)), bf(rnd(M, K, seed=21))
+        ref = y.float().t() @ x.float()
+        out = torch.zeros(N, K, device="cuda")
+        ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+        close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M / 64), what="wgrad 256")
+        if M == 512:
+            first = out.clone()
+            for _ in range(10):
+                out.fill_(7.0)     # the no-split path overwrites
+                ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+                assert torch.equal(out, first), "non-deterministic result: LDS pipeline race"
+    finally:
+        ok(L.uvit_set_tn_variant(3))
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 3])
+def test_wgrad_group_with_fused_bias_sums(L, chunks):
+    """One launch for four Linears (qkv with split q / v bias sums, proj, fc1 with bias, fc2) at different token counts."""
+    from uncertainty_vit_amd.native import WgradProblem
+    Cd, Hd, M = 256, 512, 1600
+    specs = [(M, 3 * Cd, Cd, "qkv"), (1024, Cd, Cd, None), (M, Hd, Cd, "full"), (M, Cd, Hd, None)]
+    probs = (WgradProblem * len(specs))()
+    keep, refs = [], []
+    for i, (m, n, k, bias) in enumerate(specs):
+        y, x = bf(rnd(m, n, scale=0.1, seed=30 + i)), bf(rnd(m, k, seed=40 + i))
+        out = torch.full((n, k), 0.5, device="cuda")              # accumulates into the existing value
+        b1 = torch.zeros(n if bias == "full" else Cd, device="cuda") if bias else None
+        b2 = torch.zeros(Cd, device="cuda") if bias == "qkv" else None
+        keep.append((y, x, out, b1, b2))
+        q = probs[i]
+        q.Y, q.X, q.C = y.data_ptr(), x.data_ptr(), out.data_ptr()
+        q.bias, q.bias2 = (b1.data_ptr() if b1 is not None else None), (b2.data_ptr() if b2 is not None else None)
+        q.bias_end, q.bias2_begin = (n if bias == "full" else Cd), 2 * Cd
+        q.M, q.N, q.K, q.ldy, q.ldx, q.ldc = m, n, k, n, k, k
+        refs.append((y.float().t() @ x.float() + 0.5, y.float().sum(0)))
+    ok(L.uvit_set_wgrad_group_chunks(chunks))
+    try:
+        ok(L.uvit_op_wgrad_group(probs, len(specs), S()))
+    finally:
+        ok(L.uvit_set_wgrad_group_chunks(0))
+    for (y, x, out, b1, b2), (ref, colsum), (m, n, k, bias) in zip(keep, refs, specs):
+        close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(m / 64), what="grouped wgrad")
+        if bias == "full":
+            close(b1, colsum, rtol=2e-3, atol=2e-2, what="bias sums")
+        if bias == "qkv":
+            close(b1, colsum[:Cd], rtol=2e-3, atol=2e-2, what="q bias sums")
+            close(b2, colsum[2 * Cd:], rtol=2e-3, atol=2e-2, what="v bias sums")
+    # a problem that does not qualify is refused, not approximated
+    probs[0].N = 3 * Cd - 8
+    assert L.uvit_op_wgrad_group(probs, len(specs), S()) == -2
+
+
+def test_gemm_tn_256_tile_identity(L):
+    """Y = [I; 0] picks rows of an asymmetric X: exact, catches fragment / quadrant / column-map mix-ups."""
+    M, N, K = 512, 512, 256
+    y = torch.zeros(M, N, device="cuda"); y[torch.arange(M), torch.arange(M)] = 1.0
+    x = ((torch.arange(M * K).reshape(M, K) * 5 % 251) - 125).float().cuda() / 64
+    out = torch.zeros(N, K, device="cuda")
+    yb, xb = bf(y), bf(x)
+    ok(L.uvit_set_tn_variant(1))
+    try:
+        ok(L.uvit_op_gemm_tn(P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
+    finally:
+        ok(L.uvit_set_tn_variant(3))
+    torch.testing.assert_close(out, xb.float(), rtol=0, atol=0)
+
+
 def test_gemm_tn_asymmetric(L):
     M, N, K = 64, 128, 192
     y = torch.zeros(M, N, device="cuda"); y[torch.arange(M), torch.arange(M)] = 1.0     # Y^T picks rows of X

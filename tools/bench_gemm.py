@@ -59,7 +59,7 @@ def time_tn(M, N, K, iters=20):
     return us, 2.0 * M * N * K / us / 1e6
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "bench_gemm" in sys.argv[0]:
     M = 25216
     names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu"}
     print("== NT: step shapes, variants 0 (128x128, 2 WG/CU) / 1 (256x256 staggered, 1 WG/CU) ==")

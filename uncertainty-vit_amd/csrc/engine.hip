@@ -330,6 +330,8 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
 
 extern "C" int uvit_set_gemm_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
 
+extern "C" int uvit_set_tn_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_tn_variant(v); return UVIT_OK; }
+
 extern "C" int uvit_set_tn_split_target(int wgs) { uvit_gemm_set_tn_target(wgs); return UVIT_OK; }
 
 extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
@@ -625,17 +627,37 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     };
     if (e->dual && l + 2 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 2], 0));
     bf16 *dY1 = e->dY1[par], *dY2 = e->dY2[par], *dH = e->dH[par], *dqkv = e->dqkv[par];
+    // weight gradients: one grouped launch per layer (bias column sums of fc1 / q / v fused) when every Linear has
+    // 256-multiple dimensions; otherwise one launch per Linear as the operands become available
+    TnProb wg[UVIT_TN_GROUP_MAX];
+    int nwg = 0;
+    {
+        TnProb& f2 = wg[nwg++]; f2.Y = dY1; f2.X = a.a; f2.C = g + o.fc2w; f2.M = Mred; f2.Nn = C; f2.Kk = Hd; f2.ldy = C; f2.ldx = Hd; f2.ldc = Hd;
+        TnProb& f1 = wg[nwg++]; f1.Y = dH; f1.X = a.ln2; f1.C = g + o.fc1w; f1.M = Mred; f1.Nn = Hd; f1.Kk = C; f1.ldy = Hd; f1.ldx = C; f1.ldc = C;
+        f1.bias = RP(o.fc1b); f1.bias_end = Hd;
+        for (int st = 0; st < S; ++st) {
+            TnProb& pj = wg[nwg++]; pj.Y = dY2 + st * Mp * C; pj.X = a.attn + st * Mp * C; pj.C = g + off_projw(o, st);
+            pj.M = Mred1; pj.Nn = C; pj.Kk = C; pj.ldy = C; pj.ldx = C; pj.ldc = C;
+        }
+        TnProb& qk = wg[nwg++]; qk.Y = dqkv; qk.X = a.ln1; qk.C = g + o.qkvw; qk.M = Mred; qk.Nn = 3 * C; qk.Kk = C; qk.ldy = 3 * C; qk.ldx = C; qk.ldc = C;
+        if (S == 1) { qk.bias = RP(off_qb(o, 0)); qk.bias_end = C; qk.bias2 = RP(off_vb(o, 0)); qk.bias2_begin = 2 * C; }
+    }
+    const bool grouped = uvit_gemm_tn_group_ok(wg, nwg);
     // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
     for (int st = 0; st < S; ++st)
         CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
                                  RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
-    CHECK(handoff(0));
-    CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+    if (!grouped) {
+        CHECK(handoff(0));
+        CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+    }
     GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
     CHECK(uvit_gemm_nt_launch(EPI_DGELU, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));
-    CHECK(handoff(1));
-    CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));
-    CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
+    if (!grouped) {
+        CHECK(handoff(1));
+        CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));
+        CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
+    }
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
     CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
@@ -643,9 +665,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     for (int st = 0; st < S; ++st)
         CHECK(uvit_ls_bwd_launch(e->dXb + st * Mp * C, a.projout + st * Mp * C, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + st * Mp * C,
                                  RP(o.g1), RP(off_projb(o, st)), M, C, e->N, NREP, e->n_nd, s));
-    CHECK(handoff(2));
+    if (!grouped) CHECK(handoff(2));
     for (int st = 0; st < S; ++st) {
-        CHECK(uvit_gemm_tn_launch(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
+        if (!grouped) CHECK(uvit_gemm_tn_launch(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
         GemmEpi d3; d3.out = e->dAttn + st * Mp * C; d3.ldo = C;
         CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), M, C, C, C, C, &d3, s));
     }
@@ -661,11 +683,13 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     e->slab_started = true;
     CHECK(handoff(3));
-    for (int st = 0; st < S; ++st) {
-        CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
-        CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));
-    }
-    CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
+    if (!grouped || S > 1)        // two-stream: the q / v biases differ per stream while the stacked wgrad sums both
+        for (int st = 0; st < S; ++st) {
+            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
+            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));
+        }
+    if (grouped) CHECK(uvit_gemm_tn_group_launch(wg, nwg, ws));
+    else CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
@@ -744,6 +768,21 @@ extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, in
     g.ldo = ep->ldo; g.tokens = ep->tokens > 0 ? ep->tokens : 1; g.patches = ep->patches > 0 ? ep->patches : 1;
     return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st));
 }
+extern "C" int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, uvit_stream st) {
+    if (!problems || count < 1 || count > UVIT_TN_GROUP_MAX) return UVIT_ERR_ARG;
+    TnProb pr[UVIT_TN_GROUP_MAX];
+    for (int i = 0; i < count; ++i) {
+        const uvit_wgrad_problem& q = problems[i];
+        if (!q.Y_bf16 || !q.X_bf16 || !q.C) return UVIT_ERR_ARG;
+        pr[i].Y = q.Y_bf16; pr[i].X = q.X_bf16; pr[i].C = q.C; pr[i].bias = q.bias; pr[i].bias2 = q.bias2;
+        pr[i].bias_end = q.bias_end; pr[i].bias2_begin = q.bias2_begin;
+        pr[i].M = q.M; pr[i].Nn = q.N; pr[i].Kk = q.K; pr[i].ldy = q.ldy; pr[i].ldx = q.ldx; pr[i].ldc = q.ldc;
+    }
+    return uvit_gemm_tn_group_launch(pr, count, S(st));
+}
+
+extern "C" int uvit_set_wgrad_group_chunks(int chunks) { if (chunks < 0) return UVIT_ERR_ARG; uvit_gemm_set_tn_group_chunks(chunks); return UVIT_OK; }
+
 extern "C" int uvit_op_gemm_tn(const void* Y, const void* X, int M, int N, int K, int ldy, int ldx, float* C, int ldc, uvit_stream st) {
     if (!Y || !X || !C) return UVIT_ERR_ARG;
     if (hipMemsetAsync(C, 0, (size_t)N * ldc * sizeof(float), S(st)) != hipSuccess) return UVIT_ERR_LAUNCH;

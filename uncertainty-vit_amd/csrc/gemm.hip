@@ -615,10 +615,251 @@ void gemm_tn_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// TN kernel, 256x256 output tile: the staggered 8-wave structure of gemm_nt256_kernel with the token
+// dimension as the reduction.  A K-tile is 64 tokens; its four half-tiles {YL, YH, XL, XH} are
+// [64 tokens][128 columns] bf16 images (256-B rows, 16 KiB, chunk c of row r at c ^ tn_swz(r)) read with
+// ds_read_b64_tr_b16, so the phase schedule, the vmcnt counts (2 LDS-DMA per thread per half-tile) and
+// the hazard analysis are those of the NT kernel.  Output: C[n][k] (+)= sum_m Y[m][n] X[m][k], the
+// accumulators re-laid out through wave-private LDS slots: float4 stores (no split) or one fp32 atomic per
+// lane, 256 contiguous bytes per wave-instruction (split reduction).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p + 1024));     // token rows + 4
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// one segment of one output tile: K-tiles [t0, t0 + nk) of 64 tokens, rows n0.., columns k0..
+__device__ __forceinline__ void tn256_segment(char* smem, const bf16* __restrict__ Y, const bf16* __restrict__ X,
+                                              int ldy, int ldx, int n0, int k0, int t0, int nk,
+                                              float* __restrict__ C, int ldc, bool atomic, int lane, int wave,
+                                              float* __restrict__ bias = nullptr, bool accum = false) {
+    // atomic: partial sums of a split reduction, combined with fp32 atomics; otherwise this workgroup owns the tile
+    // and stores it (accum: adds it to the value already there).
+    // bias != nullptr: also accumulate the column sums of this tile's 256 Y columns (the Linear's bias gradient),
+    // bias[i] += sum_m Y[m][n0 + i], as MFMAs against an all-ones operand: wave (wm, wn) sums the 16-column group
+    // mt = wn of each Y half beside its phases 1 and 3 (2 extra MFMAs per phase).
+    const int wm = wave >> 2, wn = wave & 3;
+    // ---- loader: a wave-instruction fills 4 token rows x 256 B; this wave issues instructions {wave, 8 + wave}
+    const bf16* src[4][2];                             // [YL, YH, XL, XH][instruction]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 8 + wave) * 4 + (lane >> 4);
+        const int sc = ((lane & 15) ^ tn_swz(row)) * 8;            // source column inside the half-tile
+        const size_t mrow = (size_t)t0 * BK + row;
+        // a wave's 2 x 32 output columns are adjacent: XL column c <-> k0 + 64 (c / 32) + c % 32, XH + 32
+        const int xc = (sc >> 5) * 64 + (sc & 31);
+        src[0][j] = Y + mrow * ldy + n0 + sc;
+        src[1][j] = Y + mrow * ldy + n0 + 128 + sc;
+        src[2][j] = X + mrow * ldx + k0 + xc;
+        src[3][j] = X + mrow * ldx + k0 + xc + 32;
+    }
+    const size_t ystep = (size_t)BK * ldy, xstep = (size_t)BK * ldx;
+    auto issue = [&](int kind, int t) {
+        if (t < nk) {
+            char* dst = smem + (t & 1) * (4 * HALF_BYTES) + kind * HALF_BYTES + wave * 1024;
+            const size_t step = kind < 2 ? ystep : xstep;
+            glds16(src[kind][0] + t * step, dst);
+            glds16(src[kind][1] + t * step, dst + 8 * 1024);
+        }
+    };
+    // ---- fragments: element j of lane (g, i) = tile[token 32 kk + 8g + j][col0 + i]
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int r0 = 8 * g + q, swz = tn_swz(r0);
+    int yoff[4], xoff[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) yoff[mt] = r0 * 256 + (((wm * 8 + mt * 2 + (pp >> 1)) ^ swz) << 4) + ((pp & 1) << 3);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) xoff[nt] = r0 * 256 + (((wn * 4 + nt * 2 + (pp >> 1)) ^ swz) << 4) + ((pp & 1) << 3);
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 yf[4][2], x0f[2][2], x1f[2][2];
+    f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bf16 one = (bf16)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#define BIAS_MMA(mq) do { if (bias) { \
+        if (wn == 0) { bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[0][0], bacc[mq], 0, 0, 0); bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[0][1], bacc[mq], 0, 0, 0); } \
+        else if (wn == 1) { bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[1][0], bacc[mq], 0, 0, 0); bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[1][1], bacc[mq], 0, 0, 0); } \
+        else if (wn == 2) { bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[2][0], bacc[mq], 0, 0, 0); bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[2][1], bacc[mq], 0, 0, 0); } \
+        else { bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[3][0], bacc[mq], 0, 0, 0); bacc[mq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[3][1], bacc[mq], 0, 0, 0); } } } while (0)
+
+#define LOAD_Y(half_base) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { \
+        yf[mt][0] = tr_pair((half_base) + yoff[mt]); yf[mt][1] = tr_pair((half_base) + yoff[mt] + 8192); }
+#define LOAD_X(dst, half_base) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) { \
+        dst[nt][0] = tr_pair((half_base) + xoff[nt]); dst[nt][1] = tr_pair((half_base) + xoff[nt] + 8192); }
+    // D[i = k_local][j = n_local]: lane li <-> output row n, registers <-> 4 consecutive output columns k
+#define MMA(mq, nq, xfr) do { __builtin_amdgcn_s_setprio(1); \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
+            acc[mq][nq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfr[nt][kk], yf[mt][kk], acc[mq][nq][mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0); } while (0)
+
+    RAW_BARRIER();                                     // a previous segment's staging slots are drained
+    issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
+    issue(0, 1); issue(2, 1);
+    if (nk >= 2) VM_WAIT(8); else VM_WAIT(4);          // YL0, XL0 landed
+    RAW_BARRIER();
+    if (wm == 1) RAW_BARRIER();                        // the stagger
+
+    for (int t = 0; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * (4 * HALF_BYTES);
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
+        // ---- phase 0: quadrant (0,0) <- YL, XL
+        LOAD_X(x0f, buf + 2 * HALF_BYTES);
+        LOAD_Y(buf);
+        issue(3, t + 1);
+        if (has1) VM_WAIT(8); else VM_WAIT(2);
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(0, 0, x0f);
+        RAW_BARRIER();
+        // ---- phase 1: quadrant (0,1) <- XH
+        LOAD_X(x1f, buf + 3 * HALF_BYTES);
+        issue(1, t + 1);
+        if (has1) VM_WAIT(8); else VM_WAIT(0);
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(0, 1, x1f);
+        BIAS_MMA(0);
+        RAW_BARRIER();
+        // ---- phase 2: quadrant (1,1) <- YH
+        LOAD_Y(buf + HALF_BYTES);
+        issue(0, t + 2);
+        RAW_BARRIER();
+        LDS_WAIT();
+        MMA(1, 1, x1f);
+        RAW_BARRIER();
+        // ---- phase 3: quadrant (1,0)
+        issue(2, t + 2);
+        if (has2) VM_WAIT(8); else if (has1) VM_WAIT(4);
+        RAW_BARRIER();
+        MMA(1, 0, x0f);
+        BIAS_MMA(1);
+        RAW_BARRIER();
+    }
+    if (wm == 0) RAW_BARRIER();
+#undef LOAD_Y
+#undef LOAD_X
+#undef MMA
+#undef BIAS_MMA
+
+    // every D row of the ones-product holds the column sums: lane (g = 0, li) register 0 <-> Y column ... + li
+    if (bias && lane < 16) {
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+            float* dst = bias + mq * 128 + wm * 64 + wn * 16 + lane;
+            if (atomic) atomicAdd(dst, bacc[mq][0]); else *dst = bacc[mq][0] + (accum ? *dst : 0.f);
+        }
+    }
+    // ---- epilogue: 8 blocks of 16 rows x 64 columns per wave, 4 fp32 slots at a time
+    char* region = smem + wave * EPI_WAVE_BYTES;
+    const int li = lane & 15;
+    const int kb = k0 + wn * 64;
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                *(f32x4*)(region + mt * EPI_SLOT_F32 + li * 256 + (((ct * 4 + g) ^ li) << 4)) = acc[mq][ct >> 1][mt][ct & 1];
+        epi_sync();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const char* slot = region + mt * EPI_SLOT_F32;
+            const int nrow = n0 + mq * 128 + wm * 64 + mt * 16;
+            if (atomic) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = *(const float*)(slot + r * 256 + ((((lane >> 2) ^ r)) << 4) + ((lane & 3) << 2));
+                    atomicAdd(C + (size_t)(nrow + r) * ldc + kb + lane, v);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 4 * i + (lane >> 4), cc = lane & 15;
+                    const f32x4 v = *(const f32x4*)(slot + row * 256 + ((cc ^ row) << 4));
+                    float4* dst = (float4*)(C + (size_t)(nrow + row) * ldc + kb + 4 * cc);
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (accum) { const float4 c0 = *dst; o.x += c0.x; o.y += c0.y; o.z += c0.z; o.w += c0.w; }
+                    *dst = o;
+                }
+            }
+        }
+        epi_sync();
+    }
+}
+
+__global__ __launch_bounds__(T_THREADS, 2)
+void gemm_tn256_kernel(const bf16* __restrict__ Y, const bf16* __restrict__ X, int M, int Nn, int Kk,
+                       int ldy, int ldx, float* __restrict__ C, int ldc, int steps_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_k = Kk / T_BN, tiles_n = Nn / T_BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_n * tiles_k);
+    const int tn = bid / tiles_k, tk = bid - tn * tiles_k;
+    const int t0 = blockIdx.y * steps_per_split;
+    const int nk = min(steps_per_split, M / BK - t0);
+    if (nk <= 0) return;
+    tn256_segment(smem, Y, X, ldy, ldx, tn * T_BM, tk * T_BN, t0, nk, C, ldc, gridDim.y > 1, lane, wave);
+}
+
+// All wgrad GEMMs of one transformer layer in one launch.  An item = (problem, output tile, token chunk); items
+// are ordered chunk-major so the workgroups resident at any time reduce the same token range of every problem
+// (their Y / X panels are shared through L2 / Infinity Cache), and the four launches' partial last rounds
+// collapse into one.  Chunks of one tile are combined with fp32 atomics (the gradient arena is zero).
+__global__ __launch_bounds__(T_THREADS, 2)
+void gemm_tn256_group_kernel(const TnGroup G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x, c = 0, p = 0;
+    bool found = false;
+    for (c = 0; c < G.max_chunks && !found; ++c)
+        for (p = 0; p < G.nprob; ++p) {
+            if (c >= G.p[p].chunks) continue;
+            const int nt = G.p[p].tiles_n * G.p[p].tiles_k;
+            if (b < nt) { found = true; break; }
+            b -= nt;
+        }
+    if (!found) return;
+    c -= 1;                                            // the for statement stepped once more after the hit
+    const TnProb& P = G.p[p];
+    const int tn = b / P.tiles_k, tk = b - tn * P.tiles_k;
+    const int t0 = c * P.chunk_steps;
+    const int nk = min(P.chunk_steps, P.nm - t0);
+    if (nk <= 0) return;
+    float* bias = nullptr;
+    if (tk == 0 && P.bias) {
+        const int n0 = tn * T_BM;                      // bias segments are multiples of 256 columns
+        if (n0 < P.bias_end) bias = P.bias + n0;
+        else if (P.bias2 && n0 >= P.bias2_begin) bias = P.bias2 + (n0 - P.bias2_begin);
+    }
+    tn256_segment(smem, (const bf16*)P.Y, (const bf16*)P.X, P.ldy, P.ldx, tn * T_BM, tk * T_BN, t0, nk, P.C, P.ldc,
+                  P.chunks > 1, lane, wave, bias, true);
+}
+
+// ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 static bool g_attr_done = false;
 static int g_variant = 3;
+static int g_tn_variant = 3;      // 0: 128x128, 1: 256x256 staggered, 3: auto
+void uvit_gemm_set_tn_variant(int v) { g_tn_variant = (v == 0 || v == 1) ? v : 3; }
+static int g_tn_group_chunks = 0;  // 0: chosen by the cost model below
+void uvit_gemm_set_tn_group_chunks(int n) { g_tn_group_chunks = n > 0 ? n : 0; }
+static int g_num_cu = 256;
 static int g_tn_target = 512;     // MI355X sweep (tools/bench_gemm.py): 512 beats 256..1536 on all four wgrad shapes
 void uvit_gemm_set_tn_target(int wgs) { g_tn_target = wgs > 0 ? wgs : 512; }
 void uvit_gemm_set_variant(int v) { g_variant = (v == 0 || v == 1) ? v : 3; }
@@ -634,6 +875,11 @@ static void gemm_init_once() {
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU);
 #undef ALLOW256
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        g_num_cu = prop.multiProcessorCount;
     g_attr_done = true;
 }
 
@@ -674,8 +920,20 @@ int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int
                         int ldc, int allow_split, hipStream_t s) {
     if (M <= 0 || (M % BK) || (Nn % 8) || (Kk % 8) || (ldy % 8) || (ldx % 8) || (ldc % 4)) return UVIT_ERR_SHAPE;
     gemm_init_once();
-    const int tiles = ((Nn + BM - 1) / BM) * ((Kk + BN - 1) / BN);
     const int nm = M / BK;
+    if (g_tn_variant == 1 && (Nn % T_BM) == 0 && (Kk % T_BN) == 0 && nm >= 8) {
+        // 256x256 tiles, one workgroup per CU: split the token reduction until ~256 workgroups exist
+        const int tiles256 = (Nn / T_BM) * (Kk / T_BN);
+        int split = allow_split ? (256 + tiles256 / 2) / tiles256 : 1;
+        if (split > nm / 4) split = nm / 4;
+        if (split < 1) split = 1;
+        const int steps256 = (nm + split - 1) / split;
+        split = (nm + steps256 - 1) / steps256;
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles256, split), dim3(T_THREADS), T_LDS_BYTES, s, (const bf16*)Y,
+                           (const bf16*)X, M, Nn, Kk, ldy, ldx, C, ldc, steps256);
+        return uvit_check_launch();
+    }
+    const int tiles = ((Nn + BM - 1) / BM) * ((Kk + BN - 1) / BN);
     // split the token reduction until ~1024 workgroups are in flight (2 resident per CU x 256 CUs, two rounds)
     int split = 1;
     if (allow_split) {
@@ -687,5 +945,64 @@ int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int
     split = (nm + steps - 1) / steps;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, split), dim3(GEMM_THREADS), TN_LDS_BYTES, s, (const bf16*)Y,
                        (const bf16*)X, M, Nn, Kk, ldy, ldx, C, ldc, steps);
+    return uvit_check_launch();
+}
+
+// Grouped wgrad: every problem needs Nn, Kk multiples of 256 (bias segments too) and a token count that is a
+// multiple of 64.  Returns UVIT_ERR_SHAPE without launching when the group does not qualify (callers fall back to
+// per-problem launches).
+bool uvit_gemm_tn_group_ok(const TnProb* probs, int n) {
+    if (n < 1 || n > UVIT_TN_GROUP_MAX || g_tn_variant == 0) return false;
+    for (int i = 0; i < n; ++i) {
+        const TnProb& q = probs[i];
+        if (q.M <= 0 || (q.M % BK) || q.M / BK < 8 || (q.Nn % T_BM) || (q.Kk % T_BN) || (q.ldy % 8) || (q.ldx % 8) || (q.ldc % 4)) return false;
+        if (q.bias && ((q.bias_end % T_BM) || (q.bias2 && (q.bias2_begin % T_BM)))) return false;
+    }
+    return true;
+}
+
+int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s) {
+    if (!uvit_gemm_tn_group_ok(probs, n)) return UVIT_ERR_SHAPE;
+    gemm_init_once();
+    TnGroup G;
+    G.nprob = n;
+    int nm_max = 0;
+    for (int i = 0; i < n; ++i) {
+        G.p[i] = probs[i];
+        G.p[i].nm = probs[i].M / BK;
+        G.p[i].tiles_n = probs[i].Nn / T_BM;
+        G.p[i].tiles_k = probs[i].Kk / T_BN;
+        nm_max = nm_max > G.p[i].nm ? nm_max : G.p[i].nm;
+    }
+    // token chunks per tile: minimise rounds x chunk main loop + the atomic traffic of combining the chunks, in units
+    // of one 64-token K-tile (~1.7 us on MI355X; fp32 atomics drain at ~1.5 TB/s = 2.6 MB per unit) -- fitted to
+    // tools/bench_tn_sweep.py (profiles/round1_wgrad_group.txt)
+    auto plan = [&](int sp, int& items) {
+        const int L = (nm_max + sp - 1) / sp;
+        items = 0;
+        for (int i = 0; i < n; ++i) items += G.p[i].tiles_n * G.p[i].tiles_k * ((G.p[i].nm + L - 1) / L);
+        return L;
+    };
+    int best_sp = 1; double best_cost = 1e30;
+    const int sp_max = nm_max / 8 < 16 ? nm_max / 8 : 16;
+    for (int sp = 1; sp <= (sp_max < 1 ? 1 : sp_max); ++sp) {
+        int items; const int L = plan(sp, items);
+        double atomic_bytes = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const int ch = (G.p[i].nm + L - 1) / L;
+            if (ch > 1) atomic_bytes += 4.0 * probs[i].Nn * probs[i].Kk * ch;
+        }
+        const double cost = (double)((items + g_num_cu - 1) / g_num_cu) * L + atomic_bytes / 2.6e6 + 6.0;
+        if (cost < best_cost) { best_cost = cost; best_sp = sp; }
+    }
+    if (g_tn_group_chunks > 0) best_sp = g_tn_group_chunks < (nm_max / 4 > 1 ? nm_max / 4 : 1) ? g_tn_group_chunks : (nm_max / 4 > 1 ? nm_max / 4 : 1);
+    int items; const int L = plan(best_sp, items);
+    G.max_chunks = 0;
+    for (int i = 0; i < n; ++i) {
+        G.p[i].chunk_steps = L;
+        G.p[i].chunks = (G.p[i].nm + L - 1) / L;
+        G.max_chunks = G.max_chunks > G.p[i].chunks ? G.max_chunks : G.p[i].chunks;
+    }
+    hipLaunchKernelGGL(gemm_tn256_group_kernel, dim3(items), dim3(T_THREADS), T_LDS_BYTES, s, G);
     return uvit_check_launch();
 }

@@ -25,10 +25,29 @@ struct GemmEpi {
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
                         const GemmEpi* epi, hipStream_t s);
 void uvit_gemm_set_variant(int v);   // 0: 128x128, 1: 256x256 staggered (1 WG/CU), 3: auto by shape
+void uvit_gemm_set_tn_variant(int v);    // 0: 128x128 kernel, 1: 256x256 staggered kernel, 3: auto
 void uvit_gemm_set_tn_target(int wgs);   // workgroups the wgrad split-K aims for
 // allow_split: partial sums are combined with fp32 atomics -> C must be zero (or hold a value to add to)
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
                         int ldc, int allow_split, hipStream_t s);
+
+// grouped wgrad (all Linear weight gradients of one layer in one launch, bias column sums fused)
+#define UVIT_TN_GROUP_MAX 6
+struct TnProb {
+    const void* Y = nullptr;         // dY [M, ldy] bf16 (rows beyond the real tokens are zero)
+    const void* X = nullptr;         // layer input [M, ldx] bf16
+    float* C = nullptr;              // dW [Nn, ldc] fp32, accumulated into (zeroed arena)
+    float* bias = nullptr;           // column sums of Y[:, 0:bias_end) (null: none)
+    float* bias2 = nullptr;          // column sums of Y[:, bias2_begin:Nn) (qkv: v_bias; null: none)
+    int bias_end = 0, bias2_begin = 0;
+    int M = 0, Nn = 0, Kk = 0, ldy = 0, ldx = 0, ldc = 0;
+    // filled by the launcher
+    int nm = 0, tiles_n = 0, tiles_k = 0, chunk_steps = 0, chunks = 0;
+};
+struct TnGroup { TnProb p[UVIT_TN_GROUP_MAX]; int nprob = 0; int max_chunks = 0; };
+bool uvit_gemm_tn_group_ok(const TnProb* probs, int n);
+int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s);
+void uvit_gemm_set_tn_group_chunks(int n);   // 0: cost model; > 0: forced token-chunk count
 
 // attention.hip
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,

@@ -53,6 +53,13 @@ class StepParams(C.Structure):
                 ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float)]
 
 
+class WgradProblem(C.Structure):
+    """uvit_wgrad_problem (include/uvit.h)."""
+    _fields_ = [("Y", C.c_void_p), ("X", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("bias2", C.c_void_p),
+                ("bias_end", C.c_int32), ("bias2_begin", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("ldy", C.c_int32), ("ldx", C.c_int32), ("ldc", C.c_int32)]
+
+
 class GemmEpilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("out", "out2", "bias", "bias2", "gamma", "resid", "rowscale", "aux", "mask",
                                            "mask_token")] + [("ldo", C.c_int32), ("tokens", C.c_int32), ("patches", C.c_int32)]
@@ -80,6 +87,9 @@ _PROTOTYPES = {
     "uvit_train_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_engine_read_stats": (_i, [_vp, _vp, _vp]),
     "uvit_set_gemm_variant": (_i, [_i]),
+    "uvit_set_tn_variant": (_i, [_i]),
+    "uvit_set_wgrad_group_chunks": (_i, [_i]),
+    "uvit_op_wgrad_group": (_i, [_vp, _i, _vp]),
     "uvit_set_tn_split_target": (_i, [_i]),
     "uvit_engine_set_streams": (_i, [_vp, _i]),
     "uvit_engine_profile": (_i, [_vp, _i, _i]),
