@@ -124,6 +124,22 @@ def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L, variant, nb, tokens, Cd, Pn):
         ok(L.uvit_set_gemm_variant(3))
 
 
+def test_gemm_nt_row_split_of_a_nearly_empty_last_round(L):
+    """Auto dispatch sends the row tiles that overflow whole rounds of 256x256 tiles (fc2: 297 tiles on 256 CUs) to the
+    128x128 kernel: the residual epilogue's per-sample drop-path scale must keep indexing by the global row."""
+    tokens, B, N, K = 197, 128, 768, 2048
+    M = B * tokens
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2))
+    b2, gam, res = rnd(N, seed=3), rnd(N, scale=0.1, seed=4), rnd(M, N, seed=5)
+    dp = (torch.arange(B, device="cuda") % 3).float() * 0.625
+    xo = torch.zeros(M, N, device="cuda"); branch = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ok(L.uvit_op_gemm_nt(3, P(a), P(w), M, N, K, K, K,
+                         C.byref(epi(out=xo, out2=branch, bias=b2, gamma=gam, resid=res, rowscale=dp, ldo=N, tokens=tokens)), S()))
+    y = a.float() @ w.float().t() + b2
+    close(branch, y, what="resid branch")
+    close(xo, res + dp.repeat_interleave(tokens)[:, None] * gam * y, rtol=5e-3, atol=5e-3, what="resid out")
+
+
 def _epilogue_modes(L, nb, tokens, Cd, Pn):
     M, Hd = nb * tokens, 512
     x = bf(rnd(M, Cd, seed=4))

@@ -24,6 +24,9 @@
 #define ROWS_PAD 224         // 14 * 16: k-steps pair two 16-row tiles
 #define IMG_BYTES (ROWS_PAD * 128)
 #define BWD_WAVES 7
+#ifndef DQ_OCC
+#define DQ_OCC 4
+#endif
 
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -112,15 +115,34 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
     __syncthreads();
     const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
 
+    // the Q fragments of a wave's next tile are fetched while it works on the current one
+    bf16x8 qn[2];
+    {
+        const int q0 = wave * 16 + li, qr0 = q0 < N ? q0 : N - 1;
+        qn[0] = *(const bf16x8*)(base + (size_t)qr0 * ld + g * 8);
+        qn[1] = *(const bf16x8*)(base + (size_t)qr0 * ld + 32 + g * 8);
+    }
     for (int qt = wave; qt < nt; qt += NW) {
         const int q = qt * 16 + li;
-        const int qr = q < N ? q : N - 1;
-        bf16x8 qf[2];
-        qf[0] = *(const bf16x8*)(base + (size_t)qr * ld + g * 8);
-        qf[1] = *(const bf16x8*)(base + (size_t)qr * ld + 32 + g * 8);
+        bf16x8 qf[2] = {qn[0], qn[1]};
         // scores in log2 units: s' = (q.k) * scale*log2(e) + biasP   (biasP is pre-multiplied by log2(e) and holds
-        // -1e30 in padded key columns, so padded keys vanish in the softmax without per-element selects)
+        // -1e30 in padded key columns, so padded keys vanish in the softmax without per-element selects).
+        // All bias rows of the tile are requested up front, into the registers that will hold the scores.
         float s[NT_MAX][4];
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            if constexpr (HAS_BIAS) {
+                if (t < nt) {
+                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                    s[t][0] = bv.x; s[t][1] = bv.y; s[t][2] = bv.z; s[t][3] = bv.w;
+                }
+            }
+        }
+        if (qt + NW < nt) {
+            const int q1 = (qt + NW) * 16 + li, qr1 = q1 < N ? q1 : N - 1;
+            qn[0] = *(const bf16x8*)(base + (size_t)qr1 * ld + g * 8);
+            qn[1] = *(const bf16x8*)(base + (size_t)qr1 * ld + 32 + g * 8);
+        }
         float mx = NEG_BIG;
         const float c = scale * LOG2E;
 #pragma unroll
@@ -129,17 +151,11 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, g), qf[0], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, 4 + g), qf[1], a, 0, 0, 0);
-                float bb[4];
-                if constexpr (HAS_BIAS) {
-                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                    bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = a[r] * c + bb[r];
+                    float bb;
+                    if constexpr (HAS_BIAS) bb = s[t][r]; else bb = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
+                    const float v = a[r] * c + bb;
                     s[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -207,7 +223,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
 // backward, query-owned: dQ, delta, and the rel-pos-bias gradient summed over a batch chunk
 // ------------------------------------------------------------------------------------------
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(BWD_WAVES * 64, 4)      // two workgroups per CU: 384 workgroups fit one round
+__global__ __launch_bounds__(BWD_WAVES * 64, DQ_OCC)
 void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                         const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
                         bf16* __restrict__ dqkv, float* __restrict__ dbias_slab, int accumulate_slab,
@@ -340,7 +356,7 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
 // backward, key-owned: dK, dV
 // ------------------------------------------------------------------------------------------
 template <bool HAS_BIAS>
-__global__ __launch_bounds__(BWD_WAVES * 64)
+__global__ __launch_bounds__(BWD_WAVES * 64, 4)      // two workgroups per CU
 void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ biasP,
                          const float* __restrict__ lse, const float* __restrict__ delta, bf16* __restrict__ dqkv,
                          int H, int N, int NP, int nhalf, float scale, uint32_t drop_thr, float inv_keep,

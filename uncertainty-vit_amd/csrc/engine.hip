@@ -150,6 +150,7 @@ struct uvit_engine {
     size_t n_nd;           // floats in the no-decay region
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
+    int ls_prefused = -1;   // layer whose MLP-branch LayerScale backward was already done by layer+1's fused LayerNorm backward
     // second stream: teacher forward beside student forward; wgrad GEMMs beside the dgrad chain
     bool dual = true;
     hipStream_t aux = nullptr;
@@ -560,7 +561,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), s));
     HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), s));
     HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), s));
-    e->slab_started = false;
+    e->slab_started = false; e->ls_prefused = -1;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
     CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
@@ -644,9 +645,13 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     const bool grouped = uvit_gemm_tn_group_ok(wg, nwg);
     // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
-    for (int st = 0; st < S; ++st)
-        CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
-                                 RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
+    // (single stream: the LayerScale backward of a branch rides in the LayerNorm backward that produces its input)
+    const bool fuse_ls = S == 1;
+    if (e->ls_prefused != l)
+        for (int st = 0; st < S; ++st)
+            CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
+                                     RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
+    e->ls_prefused = -1;
     if (!grouped) {
         CHECK(handoff(0));
         CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
@@ -660,11 +665,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
-    for (int st = 0; st < S; ++st)
-        CHECK(uvit_ls_bwd_launch(e->dXb + st * Mp * C, a.projout + st * Mp * C, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + st * Mp * C,
-                                 RP(o.g1), RP(off_projb(o, st)), M, C, e->N, NREP, e->n_nd, s));
+    if (fuse_ls) {
+        CHECK(uvit_ln_bwd_ls_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b),
+                                    a.projout, pf + o.g1, dp_ptr(e, dp_on, l, 0, 0, e->B), dY2, RP(o.g1), RP(off_projb(o, 0)), e->N,
+                                    Mall, C, NREP, e->n_nd, s));
+    } else {
+        CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
+        for (int st = 0; st < S; ++st)
+            CHECK(uvit_ls_bwd_launch(e->dXb + st * Mp * C, a.projout + st * Mp * C, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + st * Mp * C,
+                                     RP(o.g1), RP(off_projb(o, st)), M, C, e->N, NREP, e->n_nd, s));
+    }
     if (!grouped) CHECK(handoff(2));
     for (int st = 0; st < S; ++st) {
         if (!grouped) CHECK(uvit_gemm_tn_launch(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
@@ -693,7 +704,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
-    CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), Mall, C, NREP, e->n_nd, s));
+    if (fuse_ls && l > 0) {
+        // the MLP-branch LayerScale backward of layer l-1 writes dY1 of parity (l-1) & 1, last read by the wgrad of layer l+1
+        if (e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
+        const LayerOff& on = e->lo.L[l - 1];
+        CHECK(uvit_ln_bwd_ls_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b),
+                                    e->acts[l - 1].mlpout, pf + on.g2, dp_ptr(e, dp_on, l - 1, 0, 1, e->B), e->dY1[(l - 1) & 1],
+                                    RP(on.g2), RP(on.fc2b), e->N, Mall, C, NREP, e->n_nd, s));
+        e->ls_prefused = l - 1;
+    } else {
+        CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), Mall, C, NREP, e->n_nd, s));
+    }
     return UVIT_OK;
 }
 

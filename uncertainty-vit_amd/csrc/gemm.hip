@@ -204,7 +204,7 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
                 // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
                 const size_t o = (size_t)m * e.ldo + n;
                 const float4 r = *(const float4*)(e.resid + o);
-                const float dp = e.rowscale ? e.rowscale[m / e.tokens] : 1.0f;
+                const float dp = e.rowscale ? e.rowscale[(m + e.row0) / e.tokens] : 1.0f;
                 if (e.out2) {
                     const bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
                     *(bf16x4*)((bf16*)e.out2 + o) = yv;
@@ -247,9 +247,13 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A 16K | W 16K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    // consecutive ids walk N first so one XCD's chunk shares the A panel
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // tile order: XCD-contiguous chunks (T1); inside them N-groups of <= 8 column tiles walked for every row tile, so a
+    // group's W panels stay in the XCD's L2 beside the streaming A panels (wide N would otherwise re-fetch W per row)
+    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int gw = tiles_n <= 8 ? tiles_n : (tiles_n + ((tiles_n + 7) / 8) - 1) / ((tiles_n + 7) / 8);
+    int tn0 = 0;
+    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
+    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
     const int m0 = tm * BM, n0 = tn * BN;
     const int wr = wave >> 1, wc = wave & 1;
     const int g = lane >> 4, li = lane & 15;
@@ -896,6 +900,17 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0;
     int variant = shape_ok ? g_variant : 0;
     if (variant == 3) variant = (N >= 2048 || (mode == EPI_RESID && K >= 2048)) ? 1 : 0;
+    // 256x256 tiles that overflow whole rounds of the CUs by only a few tiles (fc2: 297 tiles on 256 CUs) would run
+    // a nearly empty second round: the overflowing row tiles go to the 128x128 kernel instead (second launch below)
+    int m_tail = 0;
+    if (variant == 1 && g_variant == 3 && mode != EPI_PATCH) {
+        const int tiles_n = N / T_BN, tiles = ((M + T_BM - 1) / T_BM) * tiles_n;
+        const int rounds = tiles / g_num_cu, over = tiles - rounds * g_num_cu;
+        if (rounds >= 1 && over > 0 && over * 4 <= g_num_cu) {
+            const int rows_a = (rounds * g_num_cu / tiles_n) * T_BM;
+            if (rows_a > 0 && rows_a < M) { m_tail = M - rows_a; M = rows_a; }
+        }
+    }
     const int grid = variant == 1 ? ((M + T_BM - 1) / T_BM) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
@@ -913,7 +928,23 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
         default: return UVIT_ERR_ARG;
     }
 #undef L
-    return uvit_check_launch();
+    int rc = uvit_check_launch();
+    if (rc == UVIT_OK && m_tail > 0) {
+        // remaining rows: every row-indexed epilogue operand moves with the row offset
+        GemmEpi t = *epi;
+        const size_t r0 = (size_t)M;
+        const bool f32out = mode == EPI_RESID || mode == EPI_F32 || mode == EPI_PATCH;
+        t.out = f32out ? (void*)((float*)t.out + r0 * t.ldo) : (void*)((bf16*)t.out + r0 * t.ldo);
+        if (t.out2) t.out2 = (void*)((bf16*)t.out2 + r0 * t.ldo);
+        if (t.resid) t.resid = t.resid + r0 * t.ldo;
+        if (t.aux) t.aux = (const void*)((const bf16*)t.aux + r0 * t.ldo);
+        t.row0 = epi->row0 + (int)r0;
+        const int saved = g_variant;
+        g_variant = 0;
+        rc = uvit_gemm_nt_launch(mode, a + r0 * lda, W, m_tail, N, K, lda, ldw, &t, s);
+        g_variant = saved;
+    }
+    return rc;
 }
 
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,

@@ -81,12 +81,18 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
 
 // dx = dres + rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += dy*xhat;  db += dy
 #define LNB_ROWS 32   // rows per block
-template <int NV>
+// LS = true fuses the LayerScale + DropPath backward of the branch that consumes dx next (modeling_finetune.py:295-298):
+// with e = dx * dp[row / tokens]:  dy_next = bf16(e * gamma),  dgamma += e * y_next,  dbias += dy_next  -- the fp32
+// residual gradient is then not read a second time by a separate pass.
+struct LsNext {
+    const bf16* y; const float* gamma; const float* rowscale; bf16* dy; float* dgamma; float* dbias; int tokens;
+};
+template <int NV, bool LS>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ rowidx,
                    const int* __restrict__ count, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                    const float* __restrict__ w, const float* __restrict__ dres, float* __restrict__ dx,
-                   float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride) {
+                   float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride, LsNext ls) {
     __shared__ float red[2][LN_WAVES][64 * 4];
     // column sums go to replica (block % nrep): spreads same-address atomic contention (summed once per step)
     dw += (size_t)(blockIdx.x % nrep) * rep_stride; db += (size_t)(blockIdx.x % nrep) * rep_stride;
@@ -94,8 +100,11 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
     const int nv = C >> 2;
     const int n_valid = count ? min(*count, M) : M;
     RowVec<NV> aw, ab;
+    RowVec<LS ? NV : 1> ag, ay;
 #pragma unroll
     for (int k = 0; k < NV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
+#pragma unroll
+    for (int k = 0; k < (LS ? NV : 1); ++k) { ag.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ay.v[k] = ag.v[k]; }
     const int row_end = min((int)(blockIdx.x + 1) * LNB_ROWS, n_valid);
     for (int row = blockIdx.x * LNB_ROWS + wave; row < row_end; row += LN_WAVES) {
         const int xr = rowidx ? rowidx[row] : row;
@@ -136,10 +145,49 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
                     o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
                 }
                 ((float4*)(dx + (size_t)xr * C))[i] = o;
+                if constexpr (LS) {
+                    const float dp = ls.rowscale ? ls.rowscale[xr / ls.tokens] : 1.0f;
+                    const float4 gm = ((const float4*)ls.gamma)[i];
+                    const bf16x4 yy = ((const bf16x4*)(ls.y + (size_t)xr * C))[i];
+                    const float e0 = o.x * dp, e1 = o.y * dp, e2 = o.z * dp, e3 = o.w * dp;
+                    ag.v[k].x += e0 * bf2f(yy[0]); ag.v[k].y += e1 * bf2f(yy[1]); ag.v[k].z += e2 * bf2f(yy[2]); ag.v[k].w += e3 * bf2f(yy[3]);
+                    const bf16x4 ob = {f2bf(e0 * gm.x), f2bf(e1 * gm.y), f2bf(e2 * gm.z), f2bf(e3 * gm.w)};
+                    ((bf16x4*)(ls.dy + (size_t)xr * C))[i] = ob;
+                    ay.v[k].x += bf2f(ob[0]); ay.v[k].y += bf2f(ob[1]); ay.v[k].z += bf2f(ob[2]); ay.v[k].w += bf2f(ob[3]);
+                }
             }
         }
     }
     // cross-wave reduction of the column partials, then one atomic per column per block
+    if constexpr (LS) {
+        float* dgm = ls.dgamma + (size_t)(blockIdx.x % nrep) * rep_stride;
+        float* dbs = ls.dbias + (size_t)(blockIdx.x % nrep) * rep_stride;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (64 * k < nv) {
+                __syncthreads();
+                ((float4*)red[0][wave])[lane] = ag.v[k];
+                ((float4*)red[1][wave])[lane] = ay.v[k];
+                __syncthreads();
+                if (wave == 0) {
+                    float4 sg = ((float4*)red[0][0])[lane], sy = ((float4*)red[1][0])[lane];
+#pragma unroll
+                    for (int q = 1; q < LN_WAVES; ++q) {
+                        const float4 a = ((float4*)red[0][q])[lane], c = ((float4*)red[1][q])[lane];
+                        sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
+                        sy.x += c.x; sy.y += c.y; sy.z += c.z; sy.w += c.w;
+                    }
+                    const int i = lane + 64 * k;
+                    if (i < nv) {
+                        atomicAdd(dgm + 4 * i + 0, sg.x); atomicAdd(dgm + 4 * i + 1, sg.y);
+                        atomicAdd(dgm + 4 * i + 2, sg.z); atomicAdd(dgm + 4 * i + 3, sg.w);
+                        atomicAdd(dbs + 4 * i + 0, sy.x); atomicAdd(dbs + 4 * i + 1, sy.y);
+                        atomicAdd(dbs + 4 * i + 2, sy.z); atomicAdd(dbs + 4 * i + 3, sy.w);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (64 * k < nv) {
@@ -222,6 +270,10 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     }
 }
 
+#define LN_DISPATCH2(KERNEL, FLAG, C, ...) do { const int _nv = ((C) + 255) / 256; \
+    if (_nv <= 1) hipLaunchKernelGGL((KERNEL<1, FLAG>), __VA_ARGS__); else if (_nv == 2) hipLaunchKernelGGL((KERNEL<2, FLAG>), __VA_ARGS__); \
+    else if (_nv == 3) hipLaunchKernelGGL((KERNEL<3, FLAG>), __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL((KERNEL<4, FLAG>), __VA_ARGS__); \
+    else if (_nv == 5) hipLaunchKernelGGL((KERNEL<5, FLAG>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<8, FLAG>), __VA_ARGS__); } while (0)
 #define LN_DISPATCH(KERNEL, C, ...) do { const int _nv = ((C) + 255) / 256; \
     if (_nv <= 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (_nv == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); \
     else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
@@ -246,16 +298,26 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    LN_DISPATCH(ln_bwd_kernel, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{});
+    return uvit_check_launch();
+}
+int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                          const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
+                          const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
+                          int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
+    if (ln_shape_ok(M, C) || tokens <= 0) return UVIT_ERR_SHAPE;
+    const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
+    LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,
                                const float* rstd, const float* w, float* dx, float* dw, float* db, int Mmax, int C,
                                int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    LN_DISPATCH(ln_bwd_kernel, C, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{});
     return uvit_check_launch();
 }
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,

@@ -19,6 +19,7 @@ struct GemmEpi {
     int ldo = 0;
     int tokens = 1;                  // RESID: rows per sample
     int patches = 1;                 // PATCH: rows per sample in the GEMM
+    int row0 = 0;                    // RESID: sample index of GEMM row m is (m + row0) / tokens (row-split launches)
 };
 
 // gemm.hip
@@ -72,6 +73,11 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride,
                        hipStream_t s);
+// LayerNorm backward fused with the LayerScale + DropPath backward of the branch that consumes dx next
+int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                          const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
+                          const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
+                          int M, int C, int nrep, size_t rep_stride, hipStream_t s);
 int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* rowidx, const int* count,
                                const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
                                int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
