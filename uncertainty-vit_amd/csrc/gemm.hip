@@ -828,7 +828,10 @@ void gemm_tn256_group_kernel(const TnGroup G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int b = blockIdx.x, c = 0, p = 0;
+    // XCD-contiguous item ranges (T1): the ~27 items one XCD's CUs work on at a time are neighbouring tiles of one
+    // problem, so the Y panels of a tile row and the X panels of a tile column are fetched into that L2 once
+    // (without it the launch moves 3.7x its operand bytes through the fabric and is bandwidth-bound: profiles/)
+    int b = xcd_remap(blockIdx.x, gridDim.x), c = 0, p = 0;
     bool found = false;
     for (c = 0; c < G.max_chunks && !found; ++c)
         for (p = 0; p < G.nprob; ++p) {
