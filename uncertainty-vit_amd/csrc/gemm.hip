@@ -147,10 +147,36 @@ __device__ __forceinline__ void epi_stage(const EpiCols<MODE>& c, char* slot, in
 
 __device__ __forceinline__ void epi_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// row-indexed epilogue operands of one block (DGELU: h, RESID: the residual rows), requested before the block is
+// staged so that their latency overlaps the LDS round trip instead of following it
+template <int MODE>
+struct EpiPre { bf16x8 h[2]; float4 r[4]; };
+
+template <int MODE>
+__device__ __forceinline__ EpiPre<MODE> epi_prefetch(const GemmEpi& e, int lane, int mb, int nb, int M, int N) {
+    EpiPre<MODE> p;
+    if constexpr (MODE == EPI_DGELU) {
+        const int n = nb + (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int m = mb + 8 * i + (lane >> 3); m = m < M ? m : M - 1;
+            p.h[i] = *(const bf16x8*)((const bf16*)e.aux + (size_t)m * e.ldo + (n < N ? n : 0));
+        }
+    } else if constexpr (MODE == EPI_RESID) {
+        const int n = nb + (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mb + 4 * i + (lane >> 4); m = m < M ? m : M - 1;
+            p.r[i] = *(const float4*)(e.resid + (size_t)m * e.ldo + (n < N ? n : 0));
+        }
+    }
+    return p;
+}
+
 // read one staged block back row-contiguously and finish it: block rows mb.., block columns nb..
 template <int MODE>
 __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>& c, const char* slot, int lane,
-                                          int mb, int nb, int M, int N) {
+                                          int mb, int nb, int M, int N, const EpiPre<MODE>& pre) {
     if constexpr (!stage_f32<MODE>()) {
         const int cc = lane & 7, n = nb + cc * 8;
 #pragma unroll
@@ -181,7 +207,7 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
             const f32x4 hi = *(const f32x4*)(slot + row * 256 + (((2 * cc + 1) ^ row) << 4));
             if (m >= M || n >= N) continue;
             const size_t o = (size_t)m * e.ldo + n;
-            const bf16x8 h = *(const bf16x8*)((const bf16*)e.aux + o);
+            const bf16x8 h = pre.h[i];
             bf16x8 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -203,7 +229,7 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
             } else if constexpr (MODE == EPI_RESID) {
                 // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
                 const size_t o = (size_t)m * e.ldo + n;
-                const float4 r = *(const float4*)(e.resid + o);
+                const float4 r = pre.r[i];
                 const float dp = e.rowscale ? e.rowscale[(m + e.row0) / e.tokens] : 1.0f;
                 if (e.out2) {
                     const bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
@@ -229,11 +255,13 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
         constexpr int SLOT_ = stage_f32<MODE>() ? EPI_SLOT_F32 : EPI_SLOT_BF16; \
         constexpr int GRP_ = EPI_WAVE_BYTES / SLOT_ < (NB) ? EPI_WAVE_BYTES / SLOT_ : (NB); \
         _Pragma("unroll") for (int b0_ = 0; b0_ < (NB); b0_ += GRP_) { \
+            EpiPre<MODE> pre_[GRP_]; \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) pre_[b_] = epi_prefetch<MODE>(epi, lane, MB(b0_ + b_), (nb_), M, N); \
             _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
                 epi_stage<MODE>(cols_, (region) + b_ * SLOT_, lane, ACC(b0_ + b_, 0), ACC(b0_ + b_, 1), ACC(b0_ + b_, 2), ACC(b0_ + b_, 3)); \
             epi_sync(); \
             _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
-                epi_flush<MODE>(epi, cols_, (region) + b_ * SLOT_, lane, MB(b0_ + b_), (nb_), M, N); \
+                epi_flush<MODE>(epi, cols_, (region) + b_ * SLOT_, lane, MB(b0_ + b_), (nb_), M, N, pre_[b_]); \
             epi_sync(); \
         } } while (0)
 
