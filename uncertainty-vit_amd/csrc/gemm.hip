@@ -923,14 +923,14 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
-    // variant: 0 = 128x128 (any shape, two workgroups per CU), 1 = 256x256 staggered (one per CU), 3 = auto from
-    // tools/bench_gemm.py on MI355X at M = 25216 (profiles/round1_gemm_variants_v2.txt):
-    //   N >= 2048 (qkv, fc1, fc1's GELU' dgrad): 256x256 -- 891..1188 tiles fill >= 87 % of their last round;
-    //   N = 768: 297 such tiles would leave 42 % of the second round idle -> 128x128 (1182 tiles), except the
-    //   K = 3072 residual epilogue (fc2), where the deeper pipeline still wins.
+    // variant: 0 = 128x128 (any shape, two workgroups per CU), 1 = 256x256 staggered (one per CU), 3 = auto.
+    // Auto takes the 256x256 kernel for every shape it supports.  In warm micro-benchmarks (operands resident in the
+    // Infinity Cache) the 128x128 kernel wins the N = 768 shapes by 10-25 % (profiles/round1_gemm_variants_v2.txt),
+    // but inside the step, where operands come from HBM, its one-K-tile prefetch distance costs it 28-44 % and the
+    // deeper ring of the 256x256 kernel wins everywhere: A/B of the whole step on one box 30.2 -> 29.6 ms.
     const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0;
     int variant = shape_ok ? g_variant : 0;
-    if (variant == 3) variant = (N >= 2048 || (mode == EPI_RESID && K >= 2048)) ? 1 : 0;
+    if (variant == 3) variant = 1;
     // 256x256 tiles that overflow whole rounds of the CUs by only a few tiles (fc2: 297 tiles on 256 CUs) would run
     // a nearly empty second round: the overflowing row tiles go to the 128x128 kernel instead (second launch below)
     int m_tail = 0;
