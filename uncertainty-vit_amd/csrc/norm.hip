@@ -80,7 +80,8 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
 }
 
 // dx = dres + rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += dy*xhat;  db += dy
-#define LNB_ROWS 32   // rows per block
+// rows per block are chosen by the launcher so that the grid is one balanced wave of resident blocks (25216 rows in
+// fixed 32-row blocks gave 788 blocks on 256 CUs x 4 resident: CUs with 4 blocks set the time, 30 % above the mean)
 // LS = true fuses the LayerScale + DropPath backward of the branch that consumes dx next (modeling_finetune.py:295-298):
 // with e = dx * dp[row / tokens]:  dy_next = bf16(e * gamma),  dgamma += e * y_next,  dbias += dy_next  -- the fp32
 // residual gradient is then not read a second time by a separate pass.
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(LN_WAVES * 64)
 void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ rowidx,
                    const int* __restrict__ count, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                    const float* __restrict__ w, const float* __restrict__ dres, float* __restrict__ dx,
-                   float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride, LsNext ls) {
+                   float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride, LsNext ls,
+                   int rows_per_block) {
     __shared__ float red[2][LN_WAVES][64 * 4];
     // column sums go to replica (block % nrep): spreads same-address atomic contention (summed once per step)
     dw += (size_t)(blockIdx.x % nrep) * rep_stride; db += (size_t)(blockIdx.x % nrep) * rep_stride;
@@ -105,8 +107,8 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
     for (int k = 0; k < NV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
 #pragma unroll
     for (int k = 0; k < (LS ? NV : 1); ++k) { ag.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ay.v[k] = ag.v[k]; }
-    const int row_end = min((int)(blockIdx.x + 1) * LNB_ROWS, n_valid);
-    for (int row = blockIdx.x * LNB_ROWS + wave; row < row_end; row += LN_WAVES) {
+    const int row_end = min((int)(blockIdx.x + 1) * rows_per_block, n_valid);
+    for (int row = blockIdx.x * rows_per_block + wave; row < row_end; row += LN_WAVES) {
         const int xr = rowidx ? rowidx[row] : row;
         RowVec<NV> r;
         load_row(r, x + (size_t)xr * C, C, lane);
@@ -279,6 +281,19 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
     else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
 
+static int lnb_rows(int M, int resident_blocks_per_cu) {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    const int target = ncu * resident_blocks_per_cu;
+    int rows = (M + target - 1) / target;
+    rows = ((rows + LN_WAVES - 1) / LN_WAVES) * LN_WAVES;      // every wave of a block walks the same number of rows
+    return rows < 2 * LN_WAVES ? 2 * LN_WAVES : rows;
+}
+
 static int ln_shape_ok(int M, int C) { return (M > 0 && C > 0 && (C % 4) == 0 && C <= LN_MAXV * 256) ? UVIT_OK : UVIT_ERR_SHAPE; }
 
 int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd, int M, int C,
@@ -298,8 +313,9 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{});
+    const int rpb = lnb_rows(M, 5);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{}, rpb);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
@@ -308,16 +324,18 @@ int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, con
                           int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C) || tokens <= 0) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
-    LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls);
+    const int rpb = lnb_rows(M, 4);
+    LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,
                                const float* rstd, const float* w, float* dx, float* dw, float* db, int Mmax, int C,
                                int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((Mmax + LNB_ROWS - 1) / LNB_ROWS), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{});
+    const int rpb = lnb_rows(Mmax, 5);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((Mmax + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+                       rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{}, rpb);
     return uvit_check_launch();
 }
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
