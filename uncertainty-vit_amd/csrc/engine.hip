@@ -224,7 +224,20 @@ static void fill_dims(uvit_engine* e) {
     e->H = c.num_heads; e->Kpe = c.in_chans * c.patch_size * c.patch_size;
     e->S = c.two_stream ? 2 : 1;
     e->M = e->B * e->N; e->Mpad = (int)roundup(e->M, 128); e->BP = e->B * e->P; e->BPpad = (int)roundup(e->BP, 128);
-    e->chunk = c.bias_chunk > 0 ? c.bias_chunk : 8;
+    if (c.bias_chunk > 0) {
+        e->chunk = c.bias_chunk;
+    } else {
+        // the dQ kernel runs (heads x chunks x 2 halves) workgroups, two resident per CU: take the most chunks that still
+        // fit one round (ViT-B bs=128 on 256 CUs: 19 chunks of 7 samples = 456 workgroups instead of 16 x 8 = 384)
+        int ncu = 256, dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+        const int nhalf = (e->N + 15) / 16 > 7 ? 2 : 1;
+        int max_chunks = (2 * ncu) / (e->H * nhalf);
+        if (max_chunks < 1) max_chunks = 1;
+        e->chunk = (e->B + max_chunks - 1) / max_chunks;
+        if (e->chunk < 1) e->chunk = 1;
+    }
     e->nchunk = (e->B + e->chunk - 1) / e->chunk;
     e->cur_B = e->B;
     Layout tmp_lo; build_layout(&e->cfg, tmp_lo);
