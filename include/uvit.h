@@ -136,7 +136,8 @@ int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream str
 int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
                     uvit_stream stream);
 /* Tuning / test hook for large NT GEMM shapes: 3 = auto by shape (default), 1 = 256x256 tile, staggered wave
- * groups, one workgroup per CU, 0 = 128x128 generic kernel; other values are refused. Process-wide. */
+ * groups, one workgroup per CU, 5 = the same kernel with 320x256 tiles, 0 = 128x128 generic kernel; other values
+ * are refused. Process-wide. */
 int uvit_set_gemm_variant(int v);
 /* Tuning / test hook for the wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128. */
 int uvit_set_tn_variant(int v);

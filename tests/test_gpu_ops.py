@@ -68,7 +68,7 @@ def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
     close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (2048, 768, 3072), (1100, 2304, 768), (1024, 256, 128), (1024, 256, 64)])
 def test_gemm_nt_large_tile_kernel(L, M, N, K, variant):
     """Shapes that dispatch to the 256x256 deep-prefetch kernel (N % 256 == 0, M >= 1024): parity, a ragged
@@ -89,7 +89,7 @@ def test_gemm_nt_large_tile_kernel(L, M, N, K, variant):
         ok(L.uvit_set_gemm_variant(3))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 def test_gemm_nt_large_identity(L, variant):
     """A = [I; I; ...] against an asymmetric W on the large-tile kernels: exact, catches any fragment / quadrant mix-up."""
     K, N, M = 256, 512, 2048
@@ -114,7 +114,7 @@ def test_gemm_nt_asymmetric_identity(L):
     torch.testing.assert_close(out, w.float().t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("variant,nb,tokens,Cd,Pn", [(3, 3, 10, 128, 9), (0, 11, 100, 256, 140), (1, 11, 100, 256, 140)])
+@pytest.mark.parametrize("variant,nb,tokens,Cd,Pn", [(3, 3, 10, 128, 9), (0, 11, 100, 256, 140), (1, 11, 100, 256, 140), (5, 11, 100, 256, 140)])
 def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L, variant, nb, tokens, Cd, Pn):
     """Every fused epilogue, on the 128x128 kernel (small shapes) and on each large-tile variant (ragged M = 1100)."""
     ok(L.uvit_set_gemm_variant(variant))

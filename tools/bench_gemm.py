@@ -79,10 +79,10 @@ if __name__ == "__main__" and "bench_gemm" in sys.argv[0]:
     print("== NT: step shapes, variants 0 (128x128, 2 WG/CU) / 1 (256x256 staggered, 1 WG/CU) ==")
     for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
         row = []
-        for v in (0, 1, 3):
+        for v in (0, 1, 5, 3):
             L.uvit_set_gemm_variant(v)
             us, tf = time_nt(mode, M, N, K)
-            row.append(f"{'auto' if v == 3 else 'v%d' % v}: {us:7.1f} us {tf:6.1f} TF/s")
+            row.append(f"{'auto' if v == 3 else 'v%d' % v}: {us:6.1f} us {tf:5.0f} TF")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
     L.uvit_set_gemm_variant(3)
     print("== NT: square references ==")

@@ -342,7 +342,7 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     delete e;
 }
 
-extern "C" int uvit_set_gemm_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
+extern "C" int uvit_set_gemm_variant(int v) { if (v != 0 && v != 1 && v != 3 && v != 5) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
 
 extern "C" int uvit_set_tn_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_tn_variant(v); return UVIT_OK; }
 

@@ -256,11 +256,11 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
         constexpr int GRP_ = EPI_WAVE_BYTES / SLOT_ < (NB) ? EPI_WAVE_BYTES / SLOT_ : (NB); \
         _Pragma("unroll") for (int b0_ = 0; b0_ < (NB); b0_ += GRP_) { \
             EpiPre<MODE> pre_[GRP_]; \
-            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) pre_[b_] = epi_prefetch<MODE>(epi, lane, MB(b0_ + b_), (nb_), M, N); \
-            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) if (b0_ + b_ < (NB)) pre_[b_] = epi_prefetch<MODE>(epi, lane, MB(b0_ + b_), (nb_), M, N); \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) if (b0_ + b_ < (NB)) \
                 epi_stage<MODE>(cols_, (region) + b_ * SLOT_, lane, ACC(b0_ + b_, 0), ACC(b0_ + b_, 1), ACC(b0_ + b_, 2), ACC(b0_ + b_, 3)); \
             epi_sync(); \
-            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) \
+            _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) if (b0_ + b_ < (NB)) \
                 epi_flush<MODE>(epi, cols_, (region) + b_ * SLOT_, lane, MB(b0_ + b_), (nb_), M, N, pre_[b_]); \
             epi_sync(); \
         } } while (0)
@@ -369,6 +369,7 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 #define T_THREADS 512
 #define HALF_BYTES (128 * BK * 2)          // 16 KiB
 #define T_LDS_BYTES (8 * HALF_BYTES)       // 128 KiB
+#define T5_LDS_BYTES (2 * (2 * 24 * 1024 + 2 * HALF_BYTES))   // 160 KiB: the 320-row tile (24 KiB A half-tile slots)
 
 #define VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define LDS_WAIT() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -389,62 +390,85 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 // complete before barrier 2p+2; the leading group issues phase p+2's DMA after barrier 2p+3).
 // 4 half-tiles (64 KiB) are in flight behind every wait: vmcnt(8), exact smaller counts in the K tail.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+// MT = 16-row tiles per wave per A half: 4 -> 256-row tile, 5 -> 320-row tile (N = 768 on 256 CUs: 79 x 3 = 237 tiles
+// are ONE round where 256-row tiles need 297 = 1.16 rounds).  For MT = 5 an A half-tile holds 160 rows in a 192-row
+// (24 KiB) slot so that every wave still issues whole LDS-DMA instructions (3 per half-tile; the last 32 rows are
+// padding): LDS = 2 x (24 + 24 + 16 + 16) KiB = 160 KiB, and the counted waits become LA = 3, LB = 2 loads per thread.
+template <int MODE, int MT>
 __global__ __launch_bounds__(T_THREADS, 2)
 void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
                         int lda, int ldw, GemmEpi epi) {
+    constexpr int BM_ = 64 * MT;                       // tile rows
+    constexpr int AH_ROWS = 32 * MT;                   // rows of one A half-tile
+    constexpr int LA = MT == 4 ? 2 : 3;                // LDS-DMA instructions per wave per A half-tile
+    constexpr int A_HALF = LA * 8 * 1024;              // its LDS slot
+    constexpr int BUF = 2 * A_HALF + 2 * HALF_BYTES;   // one K-tile buffer: [AL | AH | BL | BH]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = N / T_BN, tiles_m = (M + T_BM - 1) / T_BM;
+    const int tiles_n = N / T_BN, tiles_m = (M + BM_ - 1) / BM_;
     int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
     int tn0 = 0;
     while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
     const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
-    const int m0 = tm * T_BM, n0 = tn * T_BN;
+    const int m0 = tm * BM_, n0 = tn * T_BN;
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
 
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const bf16* src[4][2];                             // [AL, AH, BL, BH][instruction]
+    // 32-bit element offsets from the (scalar) base pointers keep the loader at LA + LA + 2 + 2 VGPRs
+    uint32_t srcA[2][LA], srcB[2][2];                  // [AL, AH][instruction], [BL, BH][instruction]
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        int r = (j * 8 + wave) * 8 + srow;             // row inside the half-tile slot (rows >= AH_ROWS are padding)
+        r = r < AH_ROWS ? r : AH_ROWS - 1;
+        int ra = m0 + r;            ra = ra < M ? ra : M - 1;
+        int rb = m0 + AH_ROWS + r;  rb = rb < M ? rb : M - 1;
+        srcA[0][j] = (uint32_t)ra * (uint32_t)lda + schunk * 8;
+        srcA[1][j] = (uint32_t)rb * (uint32_t)lda + schunk * 8;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (j * 8 + wave) * 8 + srow;
-        int ra = m0 + r;        ra = ra < M ? ra : M - 1;
-        int rb = m0 + 128 + r;  rb = rb < M ? rb : M - 1;
-        src[0][j] = A + (size_t)ra * lda + schunk * 8;
-        src[1][j] = A + (size_t)rb * lda + schunk * 8;
         // a wave's 2 x 32 output columns are adjacent (BL row r <-> column 64 (r / 32) + r % 32, BH +32): full
         // 128-B lines per row in the staged epilogue
         const int cb = (r >> 5) * 64 + (r & 31);
-        src[2][j] = W + (size_t)(n0 + cb) * ldw + schunk * 8;
-        src[3][j] = W + (size_t)(n0 + cb + 32) * ldw + schunk * 8;
+        srcB[0][j] = (uint32_t)(n0 + cb) * (uint32_t)ldw + schunk * 8;
+        srcB[1][j] = (uint32_t)(n0 + cb + 32) * (uint32_t)ldw + schunk * 8;
     }
     const int nk = K / BK;
-    auto issue = [&](int kind, int t) {
+    auto issue = [&](int kind, int t) {                // kind: 0 AL, 1 AH, 2 BL, 3 BH
         if (t < nk) {
-            char* dst = smem + (t & 1) * (4 * HALF_BYTES) + kind * HALF_BYTES + wave * 1024;
-            glds16(src[kind][0] + (size_t)t * BK, dst);
-            glds16(src[kind][1] + (size_t)t * BK, dst + 8 * 1024);
+            char* buf = smem + (t & 1) * BUF;
+            const uint32_t k0 = (uint32_t)t * BK;
+            if (kind < 2) {
+                char* dst = buf + kind * A_HALF + wave * 1024;
+#pragma unroll
+                for (int j = 0; j < LA; ++j) glds16(A + (srcA[kind][j] + k0), dst + j * 8 * 1024);
+            } else {
+                char* dst = buf + 2 * A_HALF + (kind - 2) * HALF_BYTES + wave * 1024;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) glds16(W + (srcB[kind - 2][j] + k0), dst + j * 8 * 1024);
+            }
         }
     };
     const int sw0 = ((g) ^ (li & 7)) << 4, sw1 = ((4 + g) ^ (li & 7)) << 4;
-    const int a_off = (wm * 64 + li) * 128, b_off = (wn * 32 + li) * 128;
+    const int a_off = (wm * 16 * MT + li) * 128, b_off = (wn * 32 + li) * 128;
 
-    f32x4 acc[2][2][4][2];
+    f32x4 acc[2][2][MT][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < MT; ++c)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+    bf16x8 af[MT][2], b0f[2][2], b1f[2][2];
 
-#define LOAD_A(half_base) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { \
+#define LOAD_A(half_base) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { \
         af[mt][0] = *(const bf16x8*)((half_base) + a_off + mt * 2048 + sw0); \
         af[mt][1] = *(const bf16x8*)((half_base) + a_off + mt * 2048 + sw1); }
 #define LOAD_B(dst, half_base) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) { \
@@ -452,40 +476,44 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         dst[nt][1] = *(const bf16x8*)((half_base) + b_off + nt * 2048 + sw1); }
 #define MMA(mq, nq, bfr) do { __builtin_amdgcn_s_setprio(1); \
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) \
             acc[mq][nq][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][kk], af[mt][kk], acc[mq][nq][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0); } while (0)
+    // counted waits: loads per thread younger than the half-tile waited for (LA per A half-tile, 2 per B half-tile)
+#define WAIT_FULL() do { if constexpr (MT == 4) VM_WAIT(8); else VM_WAIT(10); } while (0)      /* 2 LA + 2 LB */
+#define WAIT_AB() do { if constexpr (MT == 4) VM_WAIT(4); else VM_WAIT(5); } while (0)         /* LA + LB */
+#define WAIT_A() do { if constexpr (MT == 4) VM_WAIT(2); else VM_WAIT(3); } while (0)          /* LA */
 
     // ---- prologue: AL0 BL0 BH0 AH0 AL1 BL1 (BH1, AH1 are issued in phases 0, 1 of tile 0)
     issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
     issue(0, 1); issue(2, 1);
-    if (nk >= 2) VM_WAIT(8); else VM_WAIT(4);          // AL0, BL0 landed
+    if (nk >= 2) WAIT_FULL(); else WAIT_AB();          // AL0, BL0 landed (younger: BH0 AH0 [AL1 BL1])
     RAW_BARRIER();
     if (wm == 1) RAW_BARRIER();                        // the stagger: wm = 1 runs one barrier behind
 
     for (int t = 0; t < nk; ++t) {
-        const char* buf = smem + (t & 1) * (4 * HALF_BYTES);
+        const char* buf = smem + (t & 1) * BUF;
         const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
         // ---- phase 0: quadrant (0,0) <- AL, BL
-        LOAD_B(b0f, buf + 2 * HALF_BYTES);
+        LOAD_B(b0f, buf + 2 * A_HALF);
         LOAD_A(buf);
         issue(3, t + 1);                               // BH(t+1): slot last read in phase 1 of tile t-1
-        if (has1) VM_WAIT(8); else VM_WAIT(2);         // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
+        if (has1) WAIT_FULL(); else WAIT_A();          // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
         RAW_BARRIER();
         LDS_WAIT();
         MMA(0, 0, b0f);
         RAW_BARRIER();
         // ---- phase 1: quadrant (0,1) <- BH
-        LOAD_B(b1f, buf + 3 * HALF_BYTES);
+        LOAD_B(b1f, buf + 2 * A_HALF + HALF_BYTES);
         issue(1, t + 1);                               // AH(t+1): slot last read in phase 2 of tile t-1
-        if (has1) VM_WAIT(8); else VM_WAIT(0);         // AH(t) landed
+        if (has1) WAIT_FULL(); else VM_WAIT(0);        // AH(t) landed
         RAW_BARRIER();
         LDS_WAIT();
         MMA(0, 1, b1f);
         RAW_BARRIER();
         // ---- phase 2: quadrant (1,1) <- AH
-        LOAD_A(buf + HALF_BYTES);
+        LOAD_A(buf + A_HALF);
         issue(0, t + 2);                               // AL(t+2): slot last read in phase 0
         RAW_BARRIER();
         LDS_WAIT();
@@ -493,7 +521,7 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         RAW_BARRIER();
         // ---- phase 3: quadrant (1,0), no LDS read
         issue(2, t + 2);                               // BL(t+2): slot last read in phase 0
-        if (has2) VM_WAIT(8); else if (has1) VM_WAIT(4);   // AL(t+1), BL(t+1) landed
+        if (has2) WAIT_FULL(); else if (has1) WAIT_AB();   // AL(t+1), BL(t+1) landed (younger: BH AH (t+1) [AL BL (t+2)])
         RAW_BARRIER();
         MMA(1, 0, b0f);
         RAW_BARRIER();
@@ -502,10 +530,13 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #undef LOAD_A
 #undef LOAD_B
 #undef MMA
+#undef WAIT_FULL
+#undef WAIT_AB
+#undef WAIT_A
 
-#define ACC1(b, ct) acc[(b) >> 2][(ct) >> 1][(b) & 3][(ct) & 1]
-#define MB1(b) (m0 + ((b) >> 2) * 128 + wm * 64 + ((b) & 3) * 16)
-    EPI_RUN(MODE, 8, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
+#define ACC1(b, ct) acc[(b) / MT][(ct) >> 1][(b) % MT][(ct) & 1]
+#define MB1(b) (m0 + ((b) / MT) * AH_ROWS + wm * 16 * MT + ((b) % MT) * 16)
+    EPI_RUN(MODE, 2 * MT, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
 #undef ACC1
 #undef MB1
 }
@@ -897,7 +928,7 @@ void uvit_gemm_set_tn_group_chunks(int n) { g_tn_group_chunks = n > 0 ? n : 0; }
 static int g_num_cu = 256;
 static int g_tn_target = 512;     // MI355X sweep (tools/bench_gemm.py): 512 beats 256..1536 on all four wgrad shapes
 void uvit_gemm_set_tn_target(int wgs) { g_tn_target = wgs > 0 ? wgs : 512; }
-void uvit_gemm_set_variant(int v) { g_variant = (v == 0 || v == 1) ? v : 3; }
+void uvit_gemm_set_variant(int v) { g_variant = (v == 0 || v == 1 || v == 5) ? v : 3; }
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
@@ -906,7 +937,8 @@ static void gemm_init_once() {
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
-#define ALLOW256(MODE) (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES)
+#define ALLOW256(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS_BYTES); } while (0)
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU);
 #undef ALLOW256
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
@@ -923,18 +955,30 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
-    // variant: 0 = 128x128 (any shape, two workgroups per CU), 1 = 256x256 staggered (one per CU), 3 = auto.
-    // Auto takes the 256x256 kernel for every shape it supports.  In warm micro-benchmarks (operands resident in the
+    // variant: 0 = 128x128 (any shape, two workgroups per CU), 1 = 256x256 staggered (one per CU), 5 = 320x256 (same
+    // kernel, 5 row tiles per wave), 3 = auto.
+    // Auto takes the staggered kernel for every shape it supports.  In warm micro-benchmarks (operands resident in the
     // Infinity Cache) the 128x128 kernel wins the N = 768 shapes by 10-25 % (profiles/round1_gemm_variants_v2.txt),
     // but inside the step, where operands come from HBM, its one-K-tile prefetch distance costs it 28-44 % and the
-    // deeper ring of the 256x256 kernel wins everywhere: A/B of the whole step on one box 30.2 -> 29.6 ms.
-    const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0;
+    // deeper ring of the staggered kernel wins everywhere: A/B of the whole step on one box 30.2 -> 29.6 ms.
+    // Tile height: 320 rows when that saves > 10 % of rounds x rows (N = 768 at M = 25216: 237 tiles = 1 round
+    // instead of 297 = 1.16 rounds of 256-row tiles).
+    const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0 &&
+                          (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;     // 32-bit operand offsets
     int variant = shape_ok ? g_variant : 0;
-    if (variant == 3) variant = 1;
-    // 256x256 tiles that overflow whole rounds of the CUs by only a few tiles (fc2: 297 tiles on 256 CUs) would run
-    // a nearly empty second round: the overflowing row tiles go to the 128x128 kernel instead (second launch below)
+    int mt = 4;
+    if (variant == 5) { variant = 1; mt = 5; }
+    else if (variant == 3) {
+        variant = 1;
+        const int tn_ = N / T_BN;
+        const long c4 = (long)((((M + 255) / 256) * tn_ + g_num_cu - 1) / g_num_cu) * 256;
+        const long c5 = (long)((((M + 319) / 320) * tn_ + g_num_cu - 1) / g_num_cu) * 320;
+        if (c5 * 10 < c4 * 9) mt = 5;
+    }
+    // 256-row tiles that overflow whole rounds of the CUs by only a few tiles would run a nearly empty last round: the
+    // overflowing row tiles go to the 128x128 kernel instead (second launch below)
     int m_tail = 0;
-    if (variant == 1 && g_variant == 3 && mode != EPI_PATCH) {
+    if (variant == 1 && mt == 4 && g_variant == 3 && mode != EPI_PATCH) {
         const int tiles_n = N / T_BN, tiles = ((M + T_BM - 1) / T_BM) * tiles_n;
         const int rounds = tiles / g_num_cu, over = tiles - rounds * g_num_cu;
         if (rounds >= 1 && over > 0 && over * 4 <= g_num_cu) {
@@ -942,10 +986,12 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
             if (rows_a > 0 && rows_a < M) { m_tail = M - rows_a; M = rows_a; }
         }
     }
-    const int grid = variant == 1 ? ((M + T_BM - 1) / T_BM) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int bm = mt == 5 ? 320 : T_BM;
+    const int grid = variant == 1 ? ((M + bm - 1) / bm) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
-#define L(MODE) do { if (variant == 1) hipLaunchKernelGGL(gemm_nt256_kernel<MODE>, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+#define L(MODE) do { if (variant == 1 && mt == 5) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 5>), dim3(grid), dim3(T_THREADS), T5_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+        else if (variant == 1) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi); } while (0)
     switch (mode) {
         case EPI_BF16: L(EPI_BF16); break;
