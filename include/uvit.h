@@ -35,7 +35,7 @@ typedef struct uvit_config {
     float ln_eps;                     /* 1e-6, modeling_cyclical.py:294 */
     float attn_drop_rate;             /* --attn_drop_rate */
     float drop_path_rate;             /* --drop_path; per-layer linspace(0, rate, depth) */
-    int32_t bias_chunk;               /* batch elements summed per rel-pos-bias slab [chunk][h][q][key] (0 = default 8) */
+    int32_t bias_chunk;               /* batch elements summed in registers per rel-pos-bias slab (0 = chosen to fill one round of dQ workgroups) */
     int32_t two_stream;               /* 1: DistVisionTransformerForCyclicalTraining (mean, cov) model, modeling_cyclical_dist.py:14-165 */
 } uvit_config;
 

@@ -438,22 +438,18 @@ def _mix32(x: np.ndarray) -> np.ndarray:
 
 
 def attn_keep_mask(seed: int, layer: int, B: int, H: int, N: int, p_drop: float, NP: int = 208) -> Tensor:
-    """(B,H,N,N) multiplier, 0 or 1/(1-p).  Mirrors `uvit_keep4` / `uvit_keep1` in csrc/common.h: a strong 32-bit key per
-    query row (row = (b*H+h)*N + q), then per key pair j = key >> 1 a cheap mix of rk + j * 0x9E3779B1 (xorshift 15,
-    24-bit multiply by 0x5BD1E9, xorshift 13); the even key takes the low, the odd key the high 16 bits and is kept
-    when that half >= int(p * 65536).  (NP is kept in the signature for callers; the hash no longer depends on it.)"""
+    """(B,H,N,N) multiplier, 0 or 1/(1-p).  Mirrors `keep4` / `keep1` in csrc/attention.hip: one 32-bit hash per
+    (query row, key pair), pair index = ((b*H+h)*N + q) * (NP/2) + (key >> 1); key takes the low (even key) or
+    high (odd key) 16 bits and is kept when that half >= int(p * 65536)."""
     if p_drop <= 0:
         return torch.ones(B, H, N, N)
     with np.errstate(over="ignore"):
         key32 = _mix32(np.uint32(seed) ^ (np.uint32(layer + 1) * np.uint32(0x9E3779B9)))
-        rk = ((np.arange(B * H * N, dtype=np.uint32) ^ key32) * np.uint32(0x9E3779B1)).astype(np.uint32)
-        rk ^= rk >> np.uint32(15)
-        rk = (rk * np.uint32(0x85EBCA77)).astype(np.uint32)
-        rk ^= rk >> np.uint32(13)
-        j = (np.arange((N + 1) // 2, dtype=np.uint32) * np.uint32(0x9E3779B1)).astype(np.uint32)
-        x = (rk[:, None] + j[None, :]).astype(np.uint32)
+        rows = (np.arange(B * H * N, dtype=np.uint64) * np.uint64(NP // 2)).astype(np.uint32)
+        pairs = (rows[:, None] + np.arange((N + 1) // 2, dtype=np.uint32)[None, :]).astype(np.uint32)
+        x = ((pairs ^ key32) * np.uint32(0x9E3779B1)).astype(np.uint32)
         x ^= x >> np.uint32(15)
-        x = (((x & np.uint32(0xFFFFFF)).astype(np.uint64) * np.uint64(0x5BD1E9)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        x = (x * np.uint32(0x85EBCA77)).astype(np.uint32)
         x ^= x >> np.uint32(13)
     halves = np.stack([x & np.uint32(0xFFFF), x >> np.uint32(16)], axis=-1).reshape(B * H * N, -1)[:, :N]
     thr = min(int(p_drop * 65536.0), 65535)

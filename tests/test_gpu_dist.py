@@ -86,7 +86,7 @@ def test_wasserstein_attention_fwd_bwd(B, H, N, p_drop):
                                P(slab), 0, chunk, B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
     close(dq_m, qm.grad, 5e-2, 2e-2 * qm.grad.abs().max().item(), "d qkv (mean stream)")
     close(dq_c, pc.grad, 5e-2, 2e-2 * pc.grad.abs().max().item(), "d qkv (cov stream, pre-ELU)")
-    close(slab.sum(0)[:, :N, :N], bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
+    close(slab.sum(0)[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
 
 
 def dist_model(cfg):

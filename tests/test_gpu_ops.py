@@ -333,12 +333,12 @@ def test_attention_fwd_bwd(L, B, H, N, p_drop):
     g = qf.grad
     scale = g.abs().max().item()
     close(dqkv, g, rtol=3e-2, atol=2e-2 * scale, what="dqkv")
-    dbias = slab.sum(0)[:, :N, :N]                      # slab is [h][q][key]
+    dbias = slab.sum(0)[:, :N, :N].transpose(1, 2)      # slab is [h][key][q]
     close(dbias, bq.grad, rtol=3e-2, atol=2e-2 * bq.grad.abs().max().item(), what="dbias")
     # accumulate flag adds on top
     ok(L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab), 1, chunk, B, H, N, 208,
                           C.c_float(0.125), C.c_float(p_drop), seed, layer, S()))
-    close(slab.sum(0)[:, :N, :N], 2 * bq.grad, rtol=3e-2, atol=4e-2 * bq.grad.abs().max().item(), what="dbias x2")
+    close(slab.sum(0)[:, :N, :N].transpose(1, 2), 2 * bq.grad, rtol=3e-2, atol=4e-2 * bq.grad.abs().max().item(), what="dbias x2")
 
 
 def test_attention_dropout_rate_and_determinism(L):
@@ -368,7 +368,7 @@ def test_relpos_gather_scatter(L):
     assert biasP[:, N:, :N].abs().sum() == 0 and torch.all(biasP[:, :, N:] == -1e30)
     slab = torch.zeros(2, H, 208, 208, device="cuda")
     dS = rnd(2, H, N, N, seed=41)                       # [slab][h][q][k]
-    slab[:, :, :N, :N] = dS                             # stored [q][key]
+    slab[:, :, :N, :N] = dS.transpose(2, 3)             # stored [key][q]
     dt = torch.zeros_like(table)
     ok(L.uvit_op_relpos_scatter(P(slab), 2, P(i32), P(dt), H, N, 208, S()))
     ref = torch.zeros_like(table)

@@ -41,7 +41,7 @@ if __name__ == "__main__":
         f = lambda: L.uvit_op_attn_fwd(P(qkv), P(biasP), P(out), P(lse), B, H, N, NP, 0.125, p, 1, 0, S())
         us = timeit(f)
         print(f"fwd  p={p}: {us:7.1f} us  {flops_fwd / us / 1e6:6.1f} TF/s")
-        for chunk in (8, 11, 13):
+        for chunk in (7, 8):
             g = lambda: L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab), 1, chunk, B, H, N, NP,
                                            0.125, p, 1, 0, S())
             us = timeit(g)

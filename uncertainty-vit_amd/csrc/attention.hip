@@ -14,7 +14,7 @@
 // accumulator tile is directly the next MFMA's operand (no LDS round trip for P / dS).
 //
 //   fwd     : S^T = K.Q^T  -> softmax over keys -> O^T = V^T.P^T            (+ LSE saved)
-//   bwd dQ  : S^T, dP^T = V.dO^T, dS^T -> dQ^T = K^T.dS^T ; dBias summed over a batch chunk in its L2-resident slab
+//   bwd dQ  : S^T, dP^T = V.dO^T, dS^T -> dQ^T = K^T.dS^T ; dBias^T accumulated over a batch chunk
 //   bwd dKV : S = Q.K^T, dP = dO.V^T  -> dV^T = dO^T.(P.D), dK^T = Q^T.dS
 #include "common.h"
 #include "uvit_internal.h"
@@ -61,6 +61,24 @@ __device__ __forceinline__ bf16x8 pack8(const float* a, const float* b) {
     return v;
 }
 
+// Dropout: one 32-bit hash per (query row, key pair); each key takes a 16-bit half and is kept when
+// half >= round(p * 65536).  pair index = (bh*N + q) * (NP/2) + (key >> 1).  Mirrored by
+// oracle/vit_oracle.py::attn_keep_mask.
+__device__ __forceinline__ uint32_t pair_hash(uint32_t key32, uint32_t pidx) {
+    uint32_t x = (pidx ^ key32) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x;
+}
+// keep flags of the 4 consecutive keys kbase..kbase+3 (kbase % 4 == 0) of one query row
+__device__ __forceinline__ void keep4(uint32_t key32, uint32_t rowpair, int kbase, uint32_t thr16, bool (&k)[4]) {
+    const uint32_t h0 = pair_hash(key32, rowpair + (kbase >> 1)), h1 = pair_hash(key32, rowpair + (kbase >> 1) + 1);
+    k[0] = (h0 & 0xFFFFu) >= thr16; k[1] = (h0 >> 16) >= thr16;
+    k[2] = (h1 & 0xFFFFu) >= thr16; k[3] = (h1 >> 16) >= thr16;
+}
+__device__ __forceinline__ bool keep1(uint32_t key32, uint32_t rowpair, int key, uint32_t thr16) {
+    const uint32_t h = pair_hash(key32, rowpair + (key >> 1));
+    return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1e30f)
 
@@ -164,7 +182,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint32_t rk = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + q);
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
 #pragma unroll
         for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
             if (ks < nt2) {
@@ -174,10 +192,10 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
                 for (int r = 0; r < 4; ++r) { pa[r] = s[t0][r]; pb[r] = t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0][r] : 0.f; }
                 if (drop_thr) {        // dropout applied while packing P: short live ranges for the hash values
                     bool k4[4];
-                    uvit_keep4(rk, t0 * 16 + 4 * g, drop_thr, k4);
+                    keep4(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pa[r] = k4[r] ? pa[r] : 0.f;
-                    uvit_keep4(rk, t1 * 16 + 4 * g, drop_thr, k4);
+                    keep4(drop_key, rowpair, t1 * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pb[r] = k4[r] ? pb[r] : 0.f;
                 }
@@ -204,11 +222,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
 // ------------------------------------------------------------------------------------------
 // backward, query-owned: dQ, delta, and the rel-pos-bias gradient summed over a batch chunk
 // ------------------------------------------------------------------------------------------
-// NTILES > 0 fixes the number of 16-token tiles at compile time (13 for the 197 tokens of ViT-B/L) and DROP the
-// dropout switch (0 off, 1 on, 2 decided at run time): with run-time conditions around every tile the compiler ends
-// each basic block with `s_waitcnt vmcnt(0)`, which put every prefetched row back on the dependency chain (the
-// kernels sat 75 % of their wave cycles in s_waitcnt).  NTILES = 0 keeps the general form for other token counts.
-template <bool HAS_BIAS, int NTILES, int DROP>
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(BWD_WAVES * 64, DQ_OCC)
 void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                         const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
@@ -225,19 +239,17 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
     const int h = hc % H, c = hc / H;
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
-    const int nt = NTILES ? NTILES : (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-    const bool drop = DROP == 2 ? drop_thr != 0 : DROP == 1;
+    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
     const int qt = half * BWD_WAVES + wave;
     const bool active = qt < nt;
     const int q = qt * 16 + li;
     const int qr = q < N ? q : N - 1;
 
-    // The rel-pos-bias gradient of this (chunk, head) is summed over the chunk's samples in its slab row
-    // slab[c][h][q][key..] by plain read-modify-write: the slab region belongs to this workgroup alone, stays in
-    // L2, and costs no registers across samples (52 accumulator VGPRs before) -- which is what lets the bias and
-    // slab rows of the next key-tile pair be requested one iteration ahead instead of on the dependency chain.
-    float* slab_q = dbias_slab ? dbias_slab + (((size_t)(c * H + h) * NP) + q) * NP + 4 * g : nullptr;
-    const float* bias_q = HAS_BIAS ? biasP + ((size_t)h * NP + q) * NP + 4 * g : nullptr;
+    float dbacc[NT_MAX][4];
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbacc[t][r] = 0.f;
 
     for (int bi = 0; bi < chunk; ++bi) {
         const int b = c * chunk + bi;
@@ -263,32 +275,15 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
         dl = group_sum4(dl);
         const float lse_q = lse[(size_t)bh * N + qr];
         if (g == 0 && q < N) delta[(size_t)bh * N + q] = dl;
-        const uint32_t rk = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + q);
-        const float c2 = scale * LOG2E;
-        const bool slab_live = accumulate_slab || bi > 0;   // otherwise the slab row starts from zero (select, no branch)
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+        const float c = scale * LOG2E;
 
-        float4 bnext[2], snext[2];
-        auto fetch = [&](int ks_) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * ks_ + tt;
-                bnext[tt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                snext[tt] = bnext[tt];
-                if (t < nt && t < NT_MAX) {
-                    if constexpr (HAS_BIAS) bnext[tt] = *(const float4*)(bias_q + t * 16);
-                    if (NTILES || slab_q) snext[tt] = *(const float4*)(slab_q + t * 16);     // (specialised form: slab required)
-                }
-            }
-        };
-        fetch(0);
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
             if (ks < nt2) {
-                const float4 bcur[2] = {bnext[0], bnext[1]}, scur[2] = {snext[0], snext[1]};
-                if (ks + 1 < nt2) fetch(ks + 1);
                 float dsv[2][4];
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
@@ -296,31 +291,31 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dsv[tt][r] = 0.f;
                     if (t < nt && t < NT_MAX) {
-                        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
-                            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], sc, 0, 0, 0);
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], s, 0, 0, 0);
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vimg, t * 16 + li, kk * 4 + g), dof[kk], dp, 0, 0, 0);
                         }
                         float bb[4];
                         if constexpr (HAS_BIAS) {
-                            bb[0] = bcur[tt].x; bb[1] = bcur[tt].y; bb[2] = bcur[tt].z; bb[3] = bcur[tt].w;
+                            const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                            bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
                         }
                         bool k4[4] = {true, true, true, true};
-                        if (drop) uvit_keep4(rk, t * 16 + 4 * g, drop_thr, k4);
+                        if (drop_thr) keep4(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            // padded keys: bias = -1e30 -> p = 0; padded query lanes are never read back
-                            const float pr = __builtin_amdgcn_exp2f(sc[r] * c2 + bb[r] - lse_q);
+                            // padded keys: bias = -1e30 -> p = 0; padded query lanes are never stored / read
+                            const float p = __builtin_amdgcn_exp2f(s[r] * c + bb[r] - lse_q);
                             const float dpv = k4[r] ? dp[r] * inv_keep : 0.f;
-                            dsv[tt][r] = pr * (dpv - dl);
+                            const float ds = p * (dpv - dl);
+                            dsv[tt][r] = ds;
+                            dbacc[t < NT_MAX ? t : 0][r] += ds;
                         }
-                        if (NTILES || slab_q)      // a fresh slab row starts from zero: select at the use, never at the load
-                            *(float4*)(slab_q + t * 16) = make_float4((slab_live ? scur[tt].x : 0.f) + dsv[tt][0], (slab_live ? scur[tt].y : 0.f) + dsv[tt][1],
-                                                                      (slab_live ? scur[tt].z : 0.f) + dsv[tt][2], (slab_live ? scur[tt].w : 0.f) + dsv[tt][3]);
                     }
                 }
                 const bf16x8 dsf = pack8(dsv[0], dsv[1]);
@@ -340,6 +335,21 @@ void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o
             }
         }
     }
+    if (dbias_slab && active) {
+        // slab[c][h][key][q]  (transposed: q is the contiguous index, 16 lanes -> 64 B)
+        float* slab = dbias_slab + ((size_t)(c * H + h) * NP) * NP;
+#pragma unroll
+        for (int t = 0; t < NT_MAX; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    float* p = slab + (size_t)key * NP + q;
+                    *p = accumulate_slab ? *p + dbacc[t][r] : dbacc[t][r];
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -356,7 +366,6 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
     char* doimg = smem + IMG_BYTES;
     float* lse_s = (float*)(smem + 2 * IMG_BYTES);
     float* dl_s = lse_s + ROWS_PAD;
-    uint32_t* rk_s = (uint32_t*)(dl_s + ROWS_PAD);     // dropout row keys of the 224 query rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int half = blockIdx.x % nhalf;
@@ -369,7 +378,6 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
     for (int i = tid; i < ROWS_PAD; i += BWD_WAVES * 64) {
         lse_s[i] = i < N ? lse[(size_t)bh * N + i] : 0.f;
         dl_s[i] = i < N ? delta[(size_t)bh * N + i] : 0.f;
-        rk_s[i] = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + i);
     }
     __syncthreads();
     const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
@@ -412,7 +420,7 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
                     if constexpr (HAS_BIAS) bv = biasP[((size_t)h * NP + q) * NP + key]; else bv = key < N ? 0.f : NEG_BIG;
                     const float p = __builtin_amdgcn_exp2f(s[r] * c + bv - lse_s[q]);
                     float dmul = 1.0f;
-                    if (drop_thr) dmul = uvit_keep1(rk_s[q], key, drop_thr) ? inv_keep : 0.f;
+                    if (drop_thr) dmul = keep1(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), key, drop_thr) ? inv_keep : 0.f;
                     pdv[tt][r] = p * dmul;
                     dsv[tt][r] = p * (dmul * dp[r] - dl_s[q]);
                 }
@@ -449,12 +457,10 @@ static void attn_init_once() {
     if (g_attn_attr) return;
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 13, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 3 * ROWS_PAD * 4);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 3 * ROWS_PAD * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 2 * ROWS_PAD * 4);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES + 2 * ROWS_PAD * 4);
     g_attn_attr = true;
 }
 
@@ -489,13 +495,10 @@ int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, co
     const int nchunk = (B + chunk - 1) / chunk;
 #define DQ_ARGS dim3(H * nchunk * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, \
         biasP, lse, delta, (bf16*)dqkv, dbias_slab, accumulate_slab, B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key
-    if (biasP && dbias_slab && nt == 13 && thr) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 13, 1>), DQ_ARGS);
-    else if (biasP && dbias_slab && nt == 13) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 13, 0>), DQ_ARGS);
-    else if (biasP) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 0, 2>), DQ_ARGS);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 0, 2>), DQ_ARGS);
+    if (biasP) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, DQ_ARGS); else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, DQ_ARGS);
 #undef DQ_ARGS
     rc = uvit_check_launch(); if (rc) return rc;
-#define DKV_ARGS dim3(B * H * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES + 3 * ROWS_PAD * 4, s, (const bf16*)qkv, (const bf16*)d_o, \
+#define DKV_ARGS dim3(B * H * nhalf), dim3(BWD_WAVES * 64), 2 * IMG_BYTES + 2 * ROWS_PAD * 4, s, (const bf16*)qkv, (const bf16*)d_o, \
         biasP, lse, delta, (bf16*)dqkv, H, N, NP, nhalf, scale, thr, inv_keep, key
     if (biasP) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, DKV_ARGS); else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, DKV_ARGS);
 #undef DKV_ARGS

@@ -81,6 +81,19 @@ __device__ __forceinline__ bf16x8 pk8(const float* a, const float* b) {
     bf16x8 v = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
     return v;
 }
+__device__ __forceinline__ uint32_t pair_hash2(uint32_t key32, uint32_t pidx) {
+    uint32_t x = (pidx ^ key32) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x;
+}
+__device__ __forceinline__ void keep4b(uint32_t key32, uint32_t rowpair, int kbase, uint32_t thr16, bool (&k)[4]) {
+    const uint32_t h0 = pair_hash2(key32, rowpair + (kbase >> 1)), h1 = pair_hash2(key32, rowpair + (kbase >> 1) + 1);
+    k[0] = (h0 & 0xFFFFu) >= thr16; k[1] = (h0 >> 16) >= thr16; k[2] = (h1 & 0xFFFFu) >= thr16; k[3] = (h1 >> 16) >= thr16;
+}
+__device__ __forceinline__ bool keep1b(uint32_t key32, uint32_t rowpair, int key, uint32_t thr16) {
+    const uint32_t h = pair_hash2(key32, rowpair + (key >> 1));
+    return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
 __device__ __forceinline__ float gsum4(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 __device__ __forceinline__ float gmax4(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
 
@@ -182,7 +195,7 @@ void attn2_fwd_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ q
         f32x4 om[4], oc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[dt] = om[dt]; }
-        const uint32_t rk = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + q);
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
 #pragma unroll
         for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
             if (ks < nt2) {
@@ -192,10 +205,10 @@ void attn2_fwd_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ q
                 for (int r = 0; r < 4; ++r) { pa[r] = s[t0][r] * f; pb[r] = t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0][r] * f : 0.f; }
                 if (drop_thr) {
                     bool k4[4];
-                    uvit_keep4(rk, t0 * 16 + 4 * g, drop_thr, k4);
+                    keep4b(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pa[r] = k4[r] ? pa[r] : 0.f;
-                    uvit_keep4(rk, t1 * 16 + 4 * g, drop_thr, k4);
+                    keep4b(drop_key, rowpair, t1 * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pb[r] = k4[r] ? pb[r] : 0.f;
                 }
@@ -294,7 +307,7 @@ void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__
         dl = gsum4(dl);                                   // delta_i = dM.mean + 2 dC.cov
         const float lse_q = lse[(size_t)bh * N + qr];
         if (g == 0 && q < N) delta[(size_t)bh * N + q] = dl;
-        const uint32_t rk = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + q);
+        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
 
         f32x4 dam[4], dac[4];
 #pragma unroll
@@ -329,7 +342,7 @@ void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__
                             for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
                         }
                         bool k4[4] = {true, true, true, true};
-                        if (drop_thr) uvit_keep4(rk, t * 16 + 4 * g, drop_thr, k4);
+                        if (drop_thr) keep4b(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float sg = sigm(2.0f * a[r] - ri - cc[r]);
@@ -380,7 +393,7 @@ void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* p = slab + (size_t)q * NP + (t * 16 + 4 * g + r);       // slab[c][h][q][key]
+                    float* p = slab + (size_t)(t * 16 + 4 * g + r) * NP + q;
                     *p = accumulate_slab ? *p + dbacc[t][r] : dbacc[t][r];
                 }
             }
@@ -401,7 +414,6 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
     float* ri_s = (float*)(smem + 4 * IMG_BYTES);
     float* lse_s = ri_s + ROWS_PAD;
     float* dl_s = lse_s + ROWS_PAD;
-    uint32_t* rk_s = (uint32_t*)(dl_s + ROWS_PAD);     // dropout row keys of the 224 query rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int half = blockIdx.x % nhalf, bh = blockIdx.x / nhalf, b = bh / H, h = bh - b * H;
@@ -413,7 +425,6 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
         ri_s[i] = 0.f;
         lse_s[i] = i < N ? lse[(size_t)bh * N + i] : 0.f;
         dl_s[i] = i < N ? delta[(size_t)bh * N + i] : 0.f;
-        rk_s[i] = uvit_drop_rowkey(drop_key, (uint32_t)bh * N + i);
     }
     __syncthreads();
     load_image_tr<TR_SIG>(am, base_m, ld, N, scale, ri_s, tid, W2_WAVES * 64);
@@ -465,7 +476,7 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
                     const float sg = sigm(2.0f * a[r] - ri_s[q] - cjv);
                     const float p = __builtin_amdgcn_exp2f(sg * LOG2E + bv - lse_s[q]);
                     bool kp = true;
-                    if (drop_thr) kp = uvit_keep1(rk_s[q], key, drop_thr);
+                    if (drop_thr) kp = keep1b(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), key, drop_thr);
                     const float pd = kp ? p * inv_keep : 0.f;
                     const float dpd = pm[r] + 2.0f * pd * pc[r];
                     const float ds = p * ((kp ? dpd * inv_keep : 0.f) - dl_s[q]);
@@ -514,7 +525,7 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
 // launchers
 // ------------------------------------------------------------------------------------------
 #define FWD2_LDS (4 * IMG_BYTES + ROWS_PAD * 4)
-#define BKV2_LDS (4 * IMG_BYTES + 4 * ROWS_PAD * 4)
+#define BKV2_LDS (4 * IMG_BYTES + 3 * ROWS_PAD * 4)
 static bool g_attr2 = false;
 static void init2() {
     if (g_attr2) return;

@@ -48,33 +48,6 @@ __device__ __forceinline__ bool uvit_keep(uint32_t key, uint32_t idx, uint32_t t
     return uvit_hash32(idx ^ key) >= thr;
 }
 
-// ---- attention dropout: counter-based keep mask (mirrored by oracle/vit_oracle.py::attn_keep_mask) ----
-//   row key  rk = mix(row ^ key32), row = (b*H + h)*N + q         (two 32-bit multiplies, once per query row)
-//   key pair x  = rk + j * 0x9E3779B1, j = key >> 1; x ^= x >> 15; x = mul24(x, 0x5BD1E9); x ^= x >> 13
-//   the even key takes the low, the odd key the high 16 bits; a key is kept when its half >= round(p * 65536).
-// The per-pair part is 6 full-rate VALU operations (v_mul_lo_u32 is quarter rate: the two-multiply hash used per
-// pair before made the attention kernels VALU-bound on their dropout masks).
-__device__ __forceinline__ uint32_t uvit_drop_rowkey(uint32_t key32, uint32_t row) {
-    uint32_t x = (row ^ key32) * 0x9E3779B1u;
-    x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
-    return x;
-}
-__device__ __forceinline__ uint32_t uvit_drop_pair(uint32_t rk, uint32_t j) {
-    uint32_t x = rk + j * 0x9E3779B1u;
-    x ^= x >> 15; x = __umul24(x, 0x5BD1E9u); x ^= x >> 13;
-    return x;
-}
-// keep flags of the 4 consecutive keys kbase..kbase+3 (kbase % 4 == 0) of the row with key rk
-__device__ __forceinline__ void uvit_keep4(uint32_t rk, int kbase, uint32_t thr16, bool (&k)[4]) {
-    const uint32_t h0 = uvit_drop_pair(rk, kbase >> 1), h1 = uvit_drop_pair(rk, (kbase >> 1) + 1);
-    k[0] = (h0 & 0xFFFFu) >= thr16; k[1] = (h0 >> 16) >= thr16;
-    k[2] = (h1 & 0xFFFFu) >= thr16; k[3] = (h1 >> 16) >= thr16;
-}
-__device__ __forceinline__ bool uvit_keep1(uint32_t rk, int key, uint32_t thr16) {
-    const uint32_t h = uvit_drop_pair(rk, key >> 1);
-    return ((key & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
-}
-
 // ---- wave (64 lanes) reductions ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -72,7 +72,7 @@ __global__ void relpos_gather_kernel(const float* __restrict__ table, const int*
     }
 }
 
-// dtable[index[q*N+k]][h] += sum_slabs slab[s][h][q][k]   (slabs hold dS summed over batch chunks and layers)
+// dtable[index[q*N+k]][h] += sum_slabs slab[s][h][k][q]   (slabs hold dS^T summed over batch chunks and layers)
 __global__ void relpos_scatter_kernel(const float* __restrict__ slab, int nslab, const int* __restrict__ index,
                                       float* __restrict__ dtable, int H, int N, int NP, int ntable) {
     extern __shared__ float tsum[];
@@ -81,9 +81,9 @@ __global__ void relpos_scatter_kernel(const float* __restrict__ slab, int nslab,
     __syncthreads();
     const int total = N * N;
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < total; i += gridDim.y * blockDim.x) {
-        const int q = i / N, k = i - q * N;
+        const int k = i / N, q = i - k * N;
         float s = 0.f;
-        for (int sl = 0; sl < nslab; ++sl) s += slab[(((size_t)sl * H + h) * NP + q) * NP + k];
+        for (int sl = 0; sl < nslab; ++sl) s += slab[(((size_t)sl * H + h) * NP + k) * NP + q];
         atomicAdd(&tsum[index[q * N + k]], s);
     }
     __syncthreads();
