@@ -570,18 +570,22 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     hipStream_t s = (hipStream_t)stream;
     const int Bc = e->B, BP = e->BP, C = e->C;
     Layout& lo = e->lo;
-    // every gradient is accumulated (split-K wgrad atomics, bias/LN/gamma column sums): zero the arena once
-    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), s));
-    HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), s));
-    HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), s));
+    // every gradient is accumulated (split-K wgrad atomics, bias/LN/gamma column sums): zero the arena once per step.
+    // With two streams the ~440 MB of memsets ride on the second stream ahead of the teacher forward (which has slack
+    // against the student forward); their first consumers run after the ev_teacher join below.
+    hipStream_t ts = e->dual ? e->aux : s;
+    if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }
+    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), ts));
+    HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), ts));
+    HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), ts));
+    HIPCHECK(hipMemsetAsync(e->dXa, 0, e->rows_alloc() * C * sizeof(float), ts));
     e->slab_started = false; e->ls_prefused = -1;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
     CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
     // teacher (EMA weights, eval mode, no grad: engine_for_cyclical.py:68-122) runs on the second stream,
     // beside the student forward (engine_for_cyclical.py:124-128); they share only read-only inputs
-    hipStream_t ts = e->dual ? e->aux : s;
-    if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }
+    if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }   // im2col / mask list
     CHECK(run_forward(e, 1, images, nullptr, Bc, false, false, 0, 0, hp, true, ts));
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_teacher, ts));
     CHECK(run_forward(e, 0, images, mask, Bc, true, hp->train_dropout != 0, hp->seed, hp->it, nullptr, true, s));
@@ -597,7 +601,6 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // head backward
     float* g = e->buf.grads;
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
-    HIPCHECK(hipMemsetAsync(e->dXa, 0, e->rows_alloc() * C * sizeof(float), s));
     for (int st = 0; st < e->S; ++st) {
         const size_t lmw = st ? lo.clmw : lo.lmw, lmb = st ? lo.clmb : lo.lmb;
         CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, BP, RP(lmb), NREP, e->n_nd, s));
