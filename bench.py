@@ -30,7 +30,7 @@ GFLOP_BY_MODEL = {"beit_base_patch16_224": 140.698, "dist_beit_base_patch16_224"
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
 ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
-TRAFFIC_BYTES = 418_000_000     # PMC: 2 x FETCH_SIZE (185 MB) + WRITE_SIZE (233 MB, mean of teacher/student launches); profiles/round1_pmc_hbm_v9.txt
+TRAFFIC_BYTES = 418_000_000     # PMC: 2 x FETCH_SIZE (185 MB) + WRITE_SIZE (233 MB, mean of teacher/student launches); profiles/round1_pmc_hbm_v10.txt
 
 
 def synthetic_batch(B, seed, device):
