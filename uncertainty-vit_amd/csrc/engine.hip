@@ -27,7 +27,7 @@ struct Layout {
     size_t cls, mask_tok, pew, peb, relt, normw, normb, lmw, lmb;
     size_t ccls, cmask_tok, cpew, cpeb, clmw, clmb;          // two-stream model only
     LayerOff L[UVIT_MAX_DEPTH];
-    size_t n_total, n_decay;
+    size_t n_total, n_decay, n_live;     // [0, n_decay) decay | [n_decay, n_live) no-decay | [n_live, n_total) frozen
     std::vector<uvit_layout_entry> entries;
 };
 
@@ -94,10 +94,6 @@ static void build_layout(const uvit_config* c, Layout& lo) {
         if (two) { lo.L[i].cqb = add(blk(i, "attn.cov_q_bias"), {C}, 0); lo.L[i].cvb = add(blk(i, "attn.cov_v_bias"), {C}, 0); }
         lo.L[i].projb = add(blk(i, "attn.proj.bias"), {C}, 0);
         if (two) lo.L[i].cprojb = add(blk(i, "attn.cov_proj.bias"), {C}, 0);
-        // attn.cov_qkv.weight is never used by the reference's forward (modeling_finetune_dist.py:127 reuses qkv.weight):
-        // its .grad stays None, so torch's AdamW never touches it (no weight decay either).  It lives in the
-        // no-decay region with a zero gradient, which leaves it exactly constant; flag 2 = "frozen".
-        if (two) lo.L[i].cqkvw = add(blk(i, "attn.cov_qkv.weight"), {3 * C, C}, 2);
         lo.L[i].n2w = add(blk(i, "norm2.weight"), {C}, 0);
         lo.L[i].n2b = add(blk(i, "norm2.bias"), {C}, 0);
         lo.L[i].fc1b = add(blk(i, "mlp.fc1.bias"), {Hd}, 0);
@@ -107,6 +103,13 @@ static void build_layout(const uvit_config* c, Layout& lo) {
     lo.normb = add("norm.bias", {C}, 0);
     lo.lmb = add("lm_head.bias", {C}, 0);
     if (two) lo.clmb = add("cov_lm_head.bias", {C}, 0);
+    lo.n_live = off;
+    // attn.cov_qkv.weight is never used by the reference's forward (modeling_finetune_dist.py:127 reuses qkv.weight):
+    // its .grad stays None, so torch's AdamW never touches it (no weight decay either).  It lives at the END of the
+    // no-decay region with a zero gradient, which leaves it exactly constant; flag 2 = "frozen".  Being last keeps its
+    // 21 M floats out of the replicated column-sum accumulators (which span [n_decay, n_live) only).
+    if (two)
+        for (int i = 0; i < c->depth; ++i) lo.L[i].cqkvw = add(blk(i, "attn.cov_qkv.weight"), {3 * C, C}, 2);
     lo.n_total = off;
 }
 
@@ -147,7 +150,7 @@ struct uvit_engine {
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
     float* grep;           // [NREP][no-decay region] replicated column-sum accumulators
-    size_t n_nd;           // floats in the no-decay region
+    size_t n_nd;           // floats in the live (not frozen) part of the no-decay region
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
     int ls_prefused = -1;   // layer whose MLP-branch LayerScale backward was already done by layer+1's fused LayerNorm backward
@@ -241,7 +244,7 @@ static void fill_dims(uvit_engine* e) {
     e->nchunk = (e->B + e->chunk - 1) / e->chunk;
     e->cur_B = e->B;
     Layout tmp_lo; build_layout(&e->cfg, tmp_lo);
-    e->n_nd = tmp_lo.n_total - tmp_lo.n_decay;
+    e->n_nd = tmp_lo.n_live - tmp_lo.n_decay;      // span of the replicated accumulators: live no-decay tensors only
 }
 
 
@@ -575,7 +578,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // against the student forward); their first consumers run after the ev_teacher join below.
     hipStream_t ts = e->dual ? e->aux : s;
     if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }
-    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_total * sizeof(float), ts));
+    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_live * sizeof(float), ts));      // frozen tensors never receive a gradient
     HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), ts));
     HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), ts));
     HIPCHECK(hipMemsetAsync(e->dXa, 0, e->rows_alloc() * C * sizeof(float), ts));
@@ -767,13 +770,13 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
     hipStream_t s = (hipStream_t)stream;
     Layout& lo = e->lo;
     HIPCHECK(hipMemsetAsync(e->sumsq, 0, sizeof(double), s));
-    CHECK(uvit_sumsq_launch(e->buf.grads, lo.n_total, e->sumsq, s));
+    CHECK(uvit_sumsq_launch(e->buf.grads, lo.n_live, e->sumsq, s));
     const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
-    CHECK(uvit_adamw_launch(e->buf.params, e->buf.grads, e->buf.adam_m, e->buf.adam_v, e->buf.params_bf16, lo.n_total, lo.n_decay,
+    CHECK(uvit_adamw_launch(e->buf.params, e->buf.grads, e->buf.adam_m, e->buf.adam_v, e->buf.params_bf16, lo.n_live, lo.n_decay,
                             hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
                             e->gnorm, s));
     CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
-    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_total, hp->ema_decay, s));
+    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_live, hp->ema_decay, s));
     return UVIT_OK;
 }
 

@@ -44,7 +44,9 @@ class GradReducer:
             self.layer_ranges.append((lo, hi))
         self.head_range = (lay["lm_head.weight"][0], model._n_decay)      # lm_head (+ cov_lm_head) weights end the decay region
         self.embed_range = (0, lay["blocks.0.attn.qkv.weight"][0])
-        self.small_range = (model._n_decay, model._arena.numel())      # every no-decay tensor, one message
+        # every live no-decay tensor, one message (frozen tensors -- decay flag 2, laid out last -- have no gradient)
+        frozen = [o for _, o, _, _, dk in model._layout if dk == 2]
+        self.small_range = (model._n_decay, min(frozen) if frozen else model._arena.numel())
         self.pending = []
 
     def reduce(self, grads, rng, engine=None, layer=None):
