@@ -664,8 +664,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     const bool grouped = uvit_gemm_tn_group_ok(wg, nwg);
     // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
-    // (single stream: the LayerScale backward of a branch rides in the LayerNorm backward that produces its input)
-    const bool fuse_ls = S == 1;
+    // (the LayerScale backward of a branch rides in the LayerNorm backward that produces its input; in the two-stream
+    //  model that kernel is launched once per stream, because drop-path scales and the proj bias differ per stream)
+    const bool fuse_ls = true;
     if (e->ls_prefused != l)
         for (int st = 0; st < S; ++st)
             CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
@@ -686,9 +687,12 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
     if (fuse_ls) {
-        CHECK(uvit_ln_bwd_ls_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b),
-                                    a.projout, pf + o.g1, dp_ptr(e, dp_on, l, 0, 0, e->B), dY2, RP(o.g1), RP(off_projb(o, 0)), e->N,
-                                    Mall, C, NREP, e->n_nd, s));
+        for (int st = 0; st < S; ++st) {
+            const size_t ro = st * Mp, eo = ro * C;
+            CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->XM[l] + eo, a.mean2 + ro, a.rstd2 + ro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
+                                        RP(o.n2w), RP(o.n2b), a.projout + eo, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + eo,
+                                        RP(o.g1), RP(off_projb(o, st)), e->N, M, C, NREP, e->n_nd, s));
+        }
     } else {
         CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
         for (int st = 0; st < S; ++st)
@@ -727,9 +731,12 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         // the MLP-branch LayerScale backward of layer l-1 writes dY1 of parity (l-1) & 1, last read by the wgrad of layer l+1
         if (e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
         const LayerOff& on = e->lo.L[l - 1];
-        CHECK(uvit_ln_bwd_ls_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b),
-                                    e->acts[l - 1].mlpout, pf + on.g2, dp_ptr(e, dp_on, l - 1, 0, 1, e->B), e->dY1[(l - 1) & 1],
-                                    RP(on.g2), RP(on.fc2b), e->N, Mall, C, NREP, e->n_nd, s));
+        for (int st = 0; st < S; ++st) {
+            const size_t ro = st * Mp, eo = ro * C;
+            CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->X[l] + eo, a.mean1 + ro, a.rstd1 + ro, pf + o.n1w, e->dXb + eo, e->dXa + eo,
+                                        RP(o.n1w), RP(o.n1b), e->acts[l - 1].mlpout + eo, pf + on.g2, dp_ptr(e, dp_on, l - 1, st, 1, e->B),
+                                        e->dY1[(l - 1) & 1] + eo, RP(on.g2), RP(on.fc2b), e->N, M, C, NREP, e->n_nd, s));
+        }
         e->ls_prefused = l - 1;
     } else {
         CHECK(uvit_ln_bwd_launch(e->dLN, e->X[l], a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b), Mall, C, NREP, e->n_nd, s));
