@@ -150,6 +150,15 @@ void attn2_fwd_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ q
         const TokFrags A = load_tok(base_m + (size_t)qr * ld, base_c + (size_t)qr * ld, g, scale);
         const float ri = gsum4(A.side);
         float s[NT_MAX][4];
+        // all bias rows of the tile are requested up front, into the registers that will hold the scores
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+            for (int t = 0; t < NT_MAX; ++t)
+                if (t < nt) {
+                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                    s[t][0] = bv.x; s[t][1] = bv.y; s[t][2] = bv.z; s[t][3] = bv.w;
+                }
+        }
         float mx = NEG_BIG;
 #pragma unroll
         for (int t = 0; t < NT_MAX; ++t) {
@@ -164,8 +173,8 @@ void attn2_fwd_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ q
                 const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
                 float bb[4];
                 if constexpr (HAS_BIAS) {
-                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                    bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bb[r] = s[t][r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
