@@ -34,7 +34,8 @@ def native_trainer(model, lr=2e-3, wd=0.05, decay=0.9998):
     return ema, opt
 
 
-def native_steps(model, ema, opt, batches, target_layers, start=0, clip=3.0, l1_beta=2.0, decay=0.9998):
+def native_steps(model, ema, opt, batches, target_layers, start=0, clip=3.0, l1_beta=2.0, decay=0.9998, l2_loss=False,
+                 loss_scale=-1, post_target_layer_norm=True):
     """Each batch through the product's train_one_epoch (one-iteration loader); returns per-step stats."""
     from uncertainty_vit_amd import engine_for_cyclical as eng, utils
     out = []
@@ -42,6 +43,7 @@ def native_steps(model, ema, opt, batches, target_layers, start=0, clip=3.0, l1_
         loader = [((x, m), torch.zeros(1))]
         st = eng.train_one_epoch(model, ema, 0, decay, decay, target_layers, loader, opt, torch.device("cuda"), 0,
                                  utils.NativeScalerWithGradNormCount(), max_norm=clip, l1_beta=l1_beta, start_steps=start + s,
-                                 layer_results="end", loss_scale=-1, target_layer_norm_last=True, post_target_layer_norm=True)
+                                 layer_results="end", loss_scale=loss_scale, target_layer_norm_last=True,
+                                 post_target_layer_norm=post_target_layer_norm, l2_loss=l2_loss)
         out.append(st)
     return out

@@ -128,6 +128,54 @@ def test_vitb_step_vs_oracle():
         torch.testing.assert_close(esd[n].cpu(), e[n], rtol=0, atol=2 * 2e-3 * 2e-4 + 1e-7)
 
 
+@pytest.mark.parametrize("variant", ["l2_loss", "beta_small", "loss_scale", "no_post_ln", "no_clip", "ema_off", "ragged_masks"])
+def test_step_hyperparameter_variants_vs_oracle(variant):
+    """The knobs of train_one_epoch that BASELINE's recipes toggle (engine_for_cyclical.py:24-32, 147-163, 182-185;
+    utils.py:375-381): two steps of the HIP path against the oracle on a small model."""
+    cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=3, num_heads=2, init_values=0.1)
+    kw = dict(l2_loss=False, l1_beta=2.0, loss_scale=-1, post_target_layer_norm=True, clip=3.0, decay=0.9998)
+    hp = dict(l2_loss=False, l1_beta=2.0, loss_scale=-1, post_target_layer_norm=True, clip_grad=3.0, ema_decay=0.9998)
+    if variant == "l2_loss":
+        kw["l2_loss"] = hp["l2_loss"] = True
+    elif variant == "beta_small":
+        kw["l1_beta"] = hp["l1_beta"] = 0.12
+    elif variant == "loss_scale":
+        kw["loss_scale"] = hp["loss_scale"] = 8.0
+    elif variant == "no_post_ln":
+        kw["post_target_layer_norm"] = hp["post_target_layer_norm"] = False
+    elif variant == "no_clip":
+        kw["clip"], hp["clip_grad"] = None, None
+    elif variant == "ema_off":
+        kw["decay"] = hp["ema_decay"] = 1.0
+    model, sd = native_model(cfg)
+    ema, opt = native_trainer(model, decay=kw["decay"])
+    B = 5
+    batches = [(closed_form_images(f"hv{variant}{s}", B, 48), exact_masks(B, 9, 4, 40 + s)) for s in range(2)]
+    if variant == "ragged_masks":      # the block-wise generator returns AT MOST n ones: 0..9 masked patches per image
+        for s, counts in enumerate(([0, 9, 1, 4, 7], [3, 0, 0, 9, 2])):
+            mk = torch.zeros(B, 9, dtype=torch.int64)
+            for i, n in enumerate(counts):
+                mk[i, torch.arange(9).roll(i + s)[:n]] = 1
+            batches[s] = (batches[s][0], mk.view(B, 3, 3))
+    st = native_steps(model, ema, opt, [(x.cuda(), m.cuda()) for x, m in batches], [1, 2], **kw)
+    p = {k: v.clone() for k, v in sd.items()}
+    e = {k: v.clone() for k, v in sd.items()}
+    m1 = {k: torch.zeros_like(v) for k, v in p.items()}
+    v1 = {k: torch.zeros_like(t) for k, t in p.items()}
+    ohp = vo.StepHParams(target_layers=(1, 2), **hp)
+    for s, (x, mk) in enumerate(batches):
+        ref = vo.train_step(p, e, m1, v1, cfg, ohp, x, mk, s + 1)
+        assert st[s]["loss"] == pytest.approx(ref.loss, rel=2e-2 if s else 5e-3), (variant, s)
+        assert st[s]["grad_norm"] == pytest.approx(ref.grad_norm, rel=5e-2), (variant, s)
+    esd = ema.module.state_dict()
+    for n in ["blocks.1.mlp.fc1.weight", "norm.weight", "blocks.2.attn.qkv.weight"]:
+        tol = 0.0 if variant == "ema_off" else 6 * 2e-3 * 2e-4 + 1e-7     # sign flips: weights differ <= 2 lr after step 1, 4 lr after step 2
+        torch.testing.assert_close(esd[n].cpu(), e[n], rtol=0, atol=tol)
+    sdn = model.state_dict()
+    for n in ["blocks.0.mlp.fc2.weight", "lm_head.weight"]:
+        torch.testing.assert_close(sdn[n].cpu(), p[n], rtol=0, atol=2 * 2 * 2e-3 + 1e-6)
+
+
 def test_dropout_step_matches_oracle_with_replayed_masks():
     """attn_drop 0.1 + drop_path 0.3: the oracle replays the kernel's counter-based masks."""
     cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=3, num_heads=2, init_values=0.1, drop_path_rate=0.3, attn_drop_rate=0.1)
