@@ -219,3 +219,57 @@ def test_vit_large_step_vs_oracle():
     for n in ["blocks.0.attn.qkv.weight", "blocks.23.mlp.fc2.weight", "blocks.11.gamma_2", "lm_head.weight"]:
         g, r = grads[n].float().cpu(), ref.grads[n]
         assert (g - r).abs().max().item() <= 8e-2 * r.abs().max().item() + 1e-9, n
+
+
+def test_full_size_step_properties():
+    """BASELINE's headline configuration (ViT-B/16, bs=128, 120 masked patches, attn-drop 0.05, drop-path 0.25, clip 3):
+    the oracle cannot run this in seconds, so the step is checked through size-independent properties --
+    reported grad-norm = norm of the gradient arena, the AdamW bound |dw| <= lr (+ decay), the EMA identity, replay
+    determinism of the counter-based dropout, and linearity of the gradient in the batch (dropout off)."""
+    cfg = vo.VitConfig(init_values=1e-4, drop_path_rate=0.25, attn_drop_rate=0.05)
+    lr, wd, decay, B = 2e-3, 0.05, 0.9998, 128
+    x = closed_form_images("full", B, 224).cuda()
+    mask = exact_masks(B, 196, 120, 77).cuda()
+
+    def one_step(dropout_cfg, xs, ms, seed=99):
+        model, _ = native_model(dropout_cfg)
+        ema, opt = native_trainer(model, lr=lr, wd=wd, decay=decay)
+        p0 = {n: t.detach().clone() for n, t in model.state_dict().items()}
+        torch.manual_seed(seed)
+        st = native_steps(model, ema, opt, [(xs, ms)], list(range(6, 12)), start=3, clip=3.0, decay=decay)[0]
+        return model, ema, p0, st
+
+    model, ema, p0, st = one_step(cfg, x, mask)
+    assert np.isfinite(st["loss"]) and 0.0 < st["loss"] < 10.0
+    g = model._grad_arena if hasattr(model, "_grad_arena") else torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    gn = float(torch.sqrt((g.double() ** 2).sum()))
+    assert st["grad_norm"] == pytest.approx(gn, rel=1e-4)
+    coef = min(1.0, 3.0 / (gn + 1e-6))
+    sd, esd = model.state_dict(), ema.module.state_dict()
+    decay_names = {n for n, p in model.named_parameters() if p.ndim > 1 and n not in ("cls_token", "pos_embed")}
+    for n, p in model.named_parameters():
+        d = sd[n] - p0[n] * ((1 - lr * wd) if n in decay_names else 1.0)
+        assert float(d.abs().max()) <= lr * (1 + 1e-3), n                    # first AdamW step: |m / sqrt(v)| <= 1
+        # where the clipped gradient is not tiny the first step is exactly -lr * sign(g)
+        big = (p.grad.abs() * coef) > 1e-5
+        if big.any():
+            torch.testing.assert_close(d[big], -lr * torch.sign(p.grad[big]), rtol=0, atol=lr * 2e-3)
+        torch.testing.assert_close(esd[n], decay * p0[n] + (1 - decay) * sd[n], rtol=0, atol=1e-7 + 2e-7 * float(p0[n].abs().max()))
+    # replay: same seed and iteration -> the same dropout masks -> the same loss (split-K atomics reorder fp32 sums)
+    _, _, _, st2 = one_step(cfg, x, mask)
+    assert st2["loss"] == pytest.approx(st["loss"], rel=1e-5)
+    _, _, _, st3 = one_step(cfg, x, mask, seed=100)
+    assert abs(st3["loss"] - st["loss"]) > 1e-7                              # another seed, another mask set
+    # linearity in the batch (no dropout): grad(128) = mean of the two 64-sample halves (every image has 120 masked rows)
+    nod = vo.VitConfig(init_values=1e-4)
+    mfull, _, _, _ = one_step(nod, x, mask)
+    gfull = {n: p.grad.clone() for n, p in mfull.named_parameters()}
+    del mfull
+    ma, _, _, _ = one_step(nod, x[:64], mask[:64])
+    ga = {n: p.grad.clone() for n, p in ma.named_parameters()}
+    del ma
+    mb, _, _, _ = one_step(nod, x[64:], mask[64:])
+    for n, p in mb.named_parameters():
+        ref = 0.5 * (ga[n] + p.grad)
+        err = float((gfull[n] - ref).abs().max())
+        assert err <= 2e-2 * float(ref.abs().max()) + 1e-9, (n, err, float(ref.abs().max()))
