@@ -236,7 +236,8 @@ static void fill_dims(uvit_engine* e) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
         const int nhalf = (e->N + 15) / 16 > 7 ? 2 : 1;
-        int max_chunks = (2 * ncu) / (e->H * nhalf);
+        const int resident = e->S == 2 ? 1 : 2;       // the two-stream kernel holds four 28-KiB images: one workgroup per CU
+        int max_chunks = (resident * ncu) / (e->H * nhalf);
         if (max_chunks < 1) max_chunks = 1;
         e->chunk = (e->B + max_chunks - 1) / max_chunks;
         if (e->chunk < 1) e->chunk = 1;
