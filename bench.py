@@ -177,7 +177,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "model": a.model, "step_mfma_frac": round(value / world * GFLOP_BY_MODEL.get(a.model, GFLOP_PER_IMAGE) * 1e9 / PEAK_BF16, 4),
                        "final_loss": round(float(stats[0]), 5)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU | EPI_GELU_DG> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU; the student launch also stores gelu'(h))",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": TRAFFIC_BYTES,
                          "algorithmic_bytes": ALGO_BYTES, "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4),

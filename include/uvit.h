@@ -148,7 +148,7 @@ int uvit_set_tn_split_target(int wgs);
  * Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
 int uvit_engine_set_streams(uvit_engine* e, int dual);
 /* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
- * fused bias+GELU, gemm_nt_kernel<EPI_GELU>) with HIP events on the stream it runs on.
+ * fused bias+GELU, gemm_nt256_kernel<EPI_GELU / EPI_GELU_DG>) with HIP events on the stream it runs on.
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */
 int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
 int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
@@ -162,7 +162,9 @@ typedef struct uvit_gemm_epilogue {
     int32_t ldo, tokens, patches;
 } uvit_gemm_epilogue;
 enum { UVIT_EPI_BF16 = 0, UVIT_EPI_QKV = 1, UVIT_EPI_GELU = 2, UVIT_EPI_RESID = 3, UVIT_EPI_F32 = 4,
-       UVIT_EPI_PATCH = 5, UVIT_EPI_DGELU = 6 };
+       UVIT_EPI_PATCH = 5, UVIT_EPI_DGELU = 6, UVIT_EPI_QKV_ELU = 7,
+       UVIT_EPI_GELU_DG = 8,   /* out = gelu(h), out2 = gelu'(h) (bf16), h = bf16(acc + bias): the training forward of Mlp.fc1 */
+       UVIT_EPI_MULAUX = 9 };  /* out = bf16(acc * aux): GELU backward against the gelu'(h) stored by mode 8 */
 
 /* C[M,N] = A[M,K] . W[N,K]^T with a fused epilogue: nn.Linear / F.linear sites of
  * modeling_finetune.py:75-82,151,186 and the Conv2d-as-GEMM at :317 */

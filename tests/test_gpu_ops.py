@@ -155,6 +155,13 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
     h_ref = x.float() @ w1.float().t() + b1
     close(h_out, h_ref, what="gelu h")
     close(a_out, F.gelu(h_out.float()), rtol=1e-2, atol=1e-2, what="gelu a")
+    # GELU_DG / MULAUX: the training pair -- gelu(h) with gelu'(h) stored, then dH = (dY @ W2) * gelu'(h)
+    a2 = torch.zeros_like(a_out); dg = torch.zeros_like(a_out)
+    ok(L.uvit_op_gemm_nt(8, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a2, out2=dg, bias=b1, ldo=Hd)), S()))
+    assert torch.equal(a2, a_out)
+    hq = h_out.float().requires_grad_(True)
+    F.gelu(hq).sum().backward()
+    close(dg, hq.grad, rtol=1e-2, atol=1e-2, what="gelu'")
     # RESID: x + dp * gamma * (a @ W2^T + b2)
     w2 = bf(rnd(Cd, Hd, scale=0.05, seed=10)); b2, gam = rnd(Cd, seed=11), rnd(Cd, scale=0.1, seed=12)
     res = rnd(M, Cd, seed=13); dp = torch.tensor([0.0] + [1.25] * (nb - 1), device="cuda")
@@ -171,6 +178,9 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
     hh = h_out.float().requires_grad_(True)
     F.gelu(hh).backward(dy.float() @ w2.float())
     close(dh, hh.grad, rtol=2e-2, atol=5e-3, what="dgelu")
+    dh2 = torch.zeros_like(dh)
+    ok(L.uvit_op_gemm_nt(9, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh2, aux=dg, ldo=Hd)), S()))
+    close(dh2, hh.grad, rtol=2e-2, atol=8e-3, what="mul-aux dgelu")
     # PATCH: rows b*P+p -> token rows b*(P+1)+1+p, masked rows take the mask token
     B, Kpe = nb - 3 if nb > 3 else 3, 768
     cols = bf(rnd(B * Pn, Kpe, seed=15)); wpe = bf(rnd(Cd, Kpe, scale=0.03, seed=16)); bpe = rnd(Cd, seed=17)

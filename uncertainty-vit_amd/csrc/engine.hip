@@ -437,7 +437,8 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
-    CHECK(uvit_gemm_nt_launch(EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
+    // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
+    CHECK(uvit_gemm_nt_launch(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
     if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
     for (int st = 0; st < S; ++st) {
         GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
@@ -678,7 +679,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
     }
     GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
-    CHECK(uvit_gemm_nt_launch(EPI_DGELU, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));
+    CHECK(uvit_gemm_nt_launch(EPI_MULAUX, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));      // dH = (dY.W2) * gelu'(h)
     if (!grouped) {
         CHECK(handoff(1));
         CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));

@@ -42,7 +42,7 @@ __device__ __forceinline__ ColVals load_cols(const GemmEpi& e, int n, int N) {
         else if (n >= 2 * C) c.b = *(const float4*)(e.bias2 + (n - 2 * C));
     } else if constexpr (MODE == EPI_BF16 || MODE == EPI_F32) {
         if (e.bias) c.b = *(const float4*)(e.bias + n);
-    } else if constexpr (MODE == EPI_GELU || MODE == EPI_PATCH) {
+    } else if constexpr (MODE == EPI_GELU || MODE == EPI_GELU_DG || MODE == EPI_PATCH) {
         c.b = *(const float4*)(e.bias + n);
         if constexpr (MODE == EPI_PATCH) c.g = *(const float4*)(e.mask_token + n);
     } else if constexpr (MODE == EPI_RESID) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ constexpr bool stage_f32() {
-    return MODE == EPI_RESID || MODE == EPI_F32 || MODE == EPI_PATCH || MODE == EPI_DGELU;
+    return MODE == EPI_RESID || MODE == EPI_F32 || MODE == EPI_PATCH || MODE == EPI_DGELU || MODE == EPI_MULAUX;
 }
 #define EPI_SLOT_BF16 2048
 #define EPI_SLOT_F32 4096
@@ -110,7 +110,7 @@ __device__ __forceinline__ EpiCols<MODE> epi_cols(const GemmEpi& e, int nb, int 
             const int n = nb + ct * 16 + 4 * (lane >> 4);
             c.pre[ct] = load_cols<MODE>(e, n < N ? n : 0, N).b;
         }
-    } else if constexpr (MODE != EPI_DGELU) {
+    } else if constexpr (MODE != EPI_DGELU && MODE != EPI_MULAUX) {
         const int n = nb + 4 * (lane & 15);
         const ColVals v = load_cols<MODE>(e, n < N ? n : 0, N);
         c.b = v.b; c.g = v.g;
@@ -155,7 +155,7 @@ struct EpiPre { bf16x8 h[2]; float4 r[4]; };
 template <int MODE>
 __device__ __forceinline__ EpiPre<MODE> epi_prefetch(const GemmEpi& e, int lane, int mb, int nb, int M, int N) {
     EpiPre<MODE> p;
-    if constexpr (MODE == EPI_DGELU) {
+    if constexpr (MODE == EPI_DGELU || MODE == EPI_MULAUX) {
         const int n = nb + (lane & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -194,11 +194,24 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
 #pragma unroll
                 for (int j = 0; j < 8; ++j) av[j] = f2bf(gelu_fast(bf2f(v[j])));
                 *(bf16x8*)((bf16*)e.out + o) = av;
+            } else if constexpr (MODE == EPI_GELU_DG) {
+                // gelu(h) and gelu'(h) from one erf / exp evaluation of the bf16-rounded h; backward multiplies by out2
+                bf16x8 av, dv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = bf2f(v[j]);
+                    float er, gs; erf_parts(x, er, gs);
+                    const float cdf = 0.5f * (1.0f + er);
+                    av[j] = f2bf(x * cdf);
+                    dv[j] = f2bf(cdf + x * 0.39894228040143268f * gs);
+                }
+                if (e.out2) *(bf16x8*)((bf16*)e.out2 + o) = dv;
+                *(bf16x8*)((bf16*)e.out + o) = av;
             } else {
                 *(bf16x8*)((bf16*)e.out + o) = v;
             }
         }
-    } else if constexpr (MODE == EPI_DGELU) {
+    } else if constexpr (MODE == EPI_DGELU || MODE == EPI_MULAUX) {
         const int cc = lane & 7, n = nb + cc * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -211,8 +224,8 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
             bf16x8 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = f2bf(lo[j] * gelu_grad_fast(bf2f(h[j])));
-                v[4 + j] = f2bf(hi[j] * gelu_grad_fast(bf2f(h[4 + j])));
+                v[j] = f2bf(lo[j] * (MODE == EPI_DGELU ? gelu_grad_fast(bf2f(h[j])) : bf2f(h[j])));
+                v[4 + j] = f2bf(hi[j] * (MODE == EPI_DGELU ? gelu_grad_fast(bf2f(h[4 + j])) : bf2f(h[4 + j])));
             }
             *(bf16x8*)((bf16*)e.out + o) = v;
         }
@@ -937,9 +950,10 @@ static void gemm_init_once() {
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
+    allow_lds(gemm_nt_kernel<EPI_GELU_DG>); allow_lds(gemm_nt_kernel<EPI_MULAUX>);
 #define ALLOW256(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS_BYTES); } while (0)
-    ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU);
+    ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU); ALLOW256(EPI_GELU_DG); ALLOW256(EPI_MULAUX);
 #undef ALLOW256
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
@@ -1001,6 +1015,8 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
         case EPI_F32: L(EPI_F32); break;
         case EPI_PATCH: L(EPI_PATCH); break;
         case EPI_DGELU: L(EPI_DGELU); break;
+        case EPI_GELU_DG: L(EPI_GELU_DG); break;
+        case EPI_MULAUX: L(EPI_MULAUX); break;
         case EPI_QKV_ELU: if (N % 3) return UVIT_ERR_SHAPE; L(EPI_QKV_ELU); break;
         default: return UVIT_ERR_ARG;
     }

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { EPI_BF16 = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_PATCH = 5, EPI_DGELU = 6, EPI_QKV_ELU = 7 };
+enum { EPI_BF16 = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3, EPI_F32 = 4, EPI_PATCH = 5, EPI_DGELU = 6, EPI_QKV_ELU = 7,
+       EPI_GELU_DG = 8,    // out = gelu(h), out2 = gelu'(h) (bf16): what backward needs of h, computed beside gelu (shared erf / exp)
+       EPI_MULAUX = 9 };   // out = acc * aux (bf16): GELU backward against the stored gelu'(h), no transcendental work
 
 struct GemmEpi {
     void* out = nullptr;             // bf16 or f32 [M, ldo]
