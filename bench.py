@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- pre-train images/sec of the data2vec ViT-B/16 step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1; N>1 launches its own ranks (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 and no RANK / WORLD_SIZE in the environment, bench.py starts N ranks itself (one process per GPU,
+`torch.distributed.run` on 127.0.0.1) BEFORE anything touches the GPU and exits with their code; under an external
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
 A "step" is one full iteration of engine_for_cyclical.train_one_epoch on one synthetic batch that
 is already resident in HBM: teacher forward -> targets -> student forward (attn-drop 0.05,
@@ -31,6 +35,10 @@ PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH
 # fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
 ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
 TRAFFIC_BYTES = 418_000_000     # PMC: 2 x FETCH_SIZE (185 MB) + WRITE_SIZE (233 MB, mean of teacher/student launches); profiles/round1_pmc_hbm_v10.txt
+# the reference's OWN engine_for_cyclical.train_one_epoch timed in the build container (tools/time_reference.py; the
+# reference cannot travel to the GPU box): bs=4, 8 threads, 3 timed steps -- quoted beside the port's figure
+REFERENCE_ENGINE_BUILD_CONTAINER = {"img_per_s": 2.292, "s_per_step": 1.745, "threads": 8, "batch": 4, "timed_steps": 3,
+                                    "source": "profiles/round2_reference_engine_cpu.json"}
 
 
 def synthetic_batch(B, seed, device):
@@ -42,23 +50,63 @@ def synthetic_batch(B, seed, device):
     return x.to(device), m.view(B, 14, 14).to(device)
 
 
-def cpu_baseline(sample_bs=4, steps=2):
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may use, capped at the GPU box's CPU share (16 per GPU) --
+    torch's default there is all 128 SMT threads of the host, which oversubscribes the share and runs slower."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def cpu_baseline(sample_bs=4, steps=3):
     """Oracle (oracle/vit_oracle.py) timed on the host cores: same step, fp32, bounded sample."""
     from oracle import vit_oracle as vo
-    cfg = vo.VitConfig(init_values=1e-4)
-    p = vo.init_params(cfg, seed=0)
-    e = {k: v.clone() for k, v in p.items()}
-    m = {k: torch.zeros_like(v) for k, v in p.items()}
-    v = {k: torch.zeros_like(t) for k, t in p.items()}
-    x, mask = synthetic_batch(sample_bs, 0, "cpu")
-    hp = vo.StepHParams()
-    vo.train_step(p, e, m, v, cfg, hp, x, mask, 1)               # warm-up
-    t0 = time.time()
-    for s in range(steps):
-        vo.train_step(p, e, m, v, cfg, hp, x, mask, s + 2)
-    dt = (time.time() - t0) / steps
-    return {"value": sample_bs / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (+1 warm-up) of the same ViT-B/16 step at bs={sample_bs}, fp32 eager PyTorch on host cores, dropout off"}
+    threads = host_threads()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        cfg = vo.VitConfig(init_values=1e-4)
+        p = vo.init_params(cfg, seed=0)
+        e = {k: v.clone() for k, v in p.items()}
+        m = {k: torch.zeros_like(v) for k, v in p.items()}
+        v = {k: torch.zeros_like(t) for k, t in p.items()}
+        x, mask = synthetic_batch(sample_bs, 0, "cpu")
+        hp = vo.StepHParams()
+        vo.train_step(p, e, m, v, cfg, hp, x, mask, 1)               # warm-up
+        t0 = time.time()
+        for s in range(steps):
+            vo.train_step(p, e, m, v, cfg, hp, x, mask, s + 2)
+        dt = (time.time() - t0) / steps
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(sample_bs / dt, 3), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} timed steps (+1 warm-up) of the same ViT-B/16 step at bs={sample_bs}, fp32 eager PyTorch, "
+                      f"torch.set_num_threads({threads}), dropout off",
+            "reference_engine_build_container": REFERENCE_ENGINE_BUILD_CONTAINER}
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start N ranks (one process per GPU) before any GPU call and mirror their exit code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if n_dev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs, this machine has {n_dev}. "
+              "Run on a node with enough GPUs, or use --gpus 1.", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launch_command(a.gpus, port, sys.argv[1:])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_command(n, port, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -69,19 +117,29 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
+    ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient all-reduce buckets (bf16 halves the xGMI bytes; AdamW accumulates in fp32 either way)")
     ap.add_argument("--model", default="beit_base_patch16_224",
                     help="beit_base_patch16_224 (headline) | dist_beit_base_patch16_224 (--stochastic two-stream, BASELINE config 3) | "
                          "beit_large_patch16_224 | dist_beit_large_patch16_224 (config 5 model)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))               # nothing has touched the GPU yet
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher set WORLD_SIZE={world}; start it as "
+              f"`python bench.py --gpus {a.gpus}` or with --nproc-per-node {a.gpus}.", file=sys.stderr)
+        sys.exit(2)
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: LOCAL_RANK {local} has no GPU ({torch.cuda.device_count()} visible).", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)     # nccl = RCCL on ROCm
 
     from uncertainty_vit_amd import optim_factory, utils
     from uncertainty_vit_amd.engine_for_cyclical import GradReducer, make_step_params, native_step
@@ -105,19 +163,22 @@ def main():
     builtins.print = _p
     opt._ensure_state()
     engine = model.engine(a.batch, teacher=ema.module, adam_m=opt.exp_avg, adam_v=opt.exp_avg_sq)
-    reducer = GradReducer(model, world > 1)
+    reducer = GradReducer(model, world > 1, comm_dtype=torch.bfloat16 if a.grad_comm_dtype == "bf16" else torch.float32)
     x, mask = synthetic_batch(a.batch, 1000 + rank, dev)
     mask = mask.reshape(a.batch, -1).contiguous()
     L = lib()
-    if os.environ.get("UVIT_TN_TARGET"):
-        L.uvit_set_tn_split_target(int(os.environ["UVIT_TN_TARGET"]))     # tuning experiments only
-    if os.environ.get("UVIT_GEMM_VARIANT"):
-        L.uvit_set_gemm_variant(int(os.environ["UVIT_GEMM_VARIANT"]))
+    if os.environ.get("UVIT_TN_TARGET") or os.environ.get("UVIT_GEMM_VARIANT"):     # tuning experiments only
+        from uncertainty_vit_amd.native import Tuning
+        tu = Tuning.default()
+        tu.tn_split_target = int(os.environ.get("UVIT_TN_TARGET", tu.tn_split_target))
+        tu.nt_variant = int(os.environ.get("UVIT_GEMM_VARIANT", tu.nt_variant))
+        check(L.uvit_engine_set_tuning(engine.h, C.byref(tu)), "set_tuning")
+    seed = 1000 + rank             # run_cyclical.py:315 seeds with seed + rank: every rank draws its own dropout / drop-path masks
 
     def step(i):
         depth = model.depth
-        hp = make_step_params(list(range(depth // 2, depth)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, 0, i,
-                              lambda_pretraining=1e-5)
+        hp = make_step_params(list(range(depth // 2, depth)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, seed, i,
+                              lambda_pretraining=1e-5, depth=depth)
         hp.lr = 2e-5       # warm-up-sized lr: random-init weights and fixed synthetic data, 2e-3 is the post-warm-up peak
         native_step(engine, reducer, x, mask, hp)
         opt.step_count += 1
@@ -144,7 +205,8 @@ def main():
     check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
     tot, n, fl = C.c_double(), C.c_int(), C.c_double()
     check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
-    ov_ms = tot.value / max(n.value, 1)
+    in_ms, in_n, flops = tot.value / max(n.value, 1), n.value, fl.value
+    alone_ms = None
     if not a.single_stream:
         # the same kernel alone on the GPU: a few extra single-stream steps right after the timed region
         check(L.uvit_engine_set_streams(engine.h, 0), "set_streams")
@@ -154,6 +216,7 @@ def main():
         fence()
         check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
         check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
+        alone_ms = tot.value / max(n.value, 1)
         check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
     stats = torch.zeros(2).pin_memory()
     check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
@@ -165,8 +228,9 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = a.batch * world * a.steps / dt
-        kern_ms = tot.value / max(n.value, 1)
-        achieved = fl.value / (kern_ms * 1e-3) / 1e12 if n.value else 0.0
+        # headline: the dominant kernel's launches INSIDE the timed region (HIP events on the stream it is launched on).  In
+        # the default two-stream schedule other kernels share the CUs with it there; "alone" is the same kernel by itself.
+        achieved = flops / (in_ms * 1e-3) / 1e12 if in_n else 0.0
         out = {
             "metric": "pretrain images/sec (ViT-B/16 224, bs=128/GPU)", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
@@ -180,10 +244,16 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU | EPI_GELU_DG> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU; the student launch also stores gelu'(h))",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": TRAFFIC_BYTES,
-                         "algorithmic_bytes": ALGO_BYTES, "launches_timed": n.value, "avg_launch_ms": round(kern_ms, 4),
-                         "measured": "HIP events on the launch stream; " + ("timed region, single stream" if a.single_stream else
-                                     "3 single-stream steps right after the timed region (kernel alone on the GPU)"),
-                         "avg_launch_ms_in_timed_region_overlapped": round(ov_ms, 4)},
+                         "algorithmic_bytes": ALGO_BYTES, "launches_timed": in_n, "avg_launch_ms": round(in_ms, 4),
+                         "flops_per_launch": flops,
+                         "measured": "HIP events on the launch stream over the timed region (" +
+                                     ("single stream: the kernel has the GPU to itself)" if a.single_stream else
+                                      "two-stream schedule: other kernels share the CUs with it)"),
+                         "alone": None if alone_ms is None else {
+                             "avg_launch_ms": round(alone_ms, 4), "achieved": round(flops / (alone_ms * 1e-3) / 1e12, 2),
+                             "frac": round(flops / (alone_ms * 1e-3) / PEAK_BF16, 4),
+                             "measured": "3 single-stream steps right after the timed region (kernel alone on the GPU)"}},
+            "rccl_ranks": world,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -87,6 +87,9 @@ typedef struct uvit_step_params {
 } uvit_step_params;
 
 int uvit_version(void);
+/* First 16 hex digits of the SHA-256 over csrc/{*.hip,*.h} (sorted by name) + include/uvit.h that the library was built
+ * from; the host side compares it with the sources on disk and refuses a stale build. */
+const char* uvit_source_hash(void);
 
 /* ---- arena layout (single source of truth for the host-side state-dict views) ---- */
 int uvit_layout_count(const uvit_config* cfg);
@@ -135,14 +138,17 @@ int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream str
 /* all of the above on one stream (single-GPU fast path) */
 int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, const uvit_step_params* hp,
                     uvit_stream stream);
-/* Tuning / test hook for large NT GEMM shapes: 3 = auto by shape (default), 1 = 256x256 tile, staggered wave
- * groups, one workgroup per CU, 5 = the same kernel with 320x256 tiles, 0 = 128x128 generic kernel; other values
- * are refused. Process-wide. */
-int uvit_set_gemm_variant(int v);
-/* Tuning / test hook for the wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128. */
-int uvit_set_tn_variant(int v);
-/* Tuning hook: number of workgroups the wgrad GEMM's token split aims for (default 512). Process-wide. */
-int uvit_set_tn_split_target(int wgs);
+/* Launch tuning.  It is an ARGUMENT (engine member / operator-call parameter), never process-wide state, so host
+ * threads that launch on different streams cannot disturb one another.
+ *   nt_variant: NT GEMM kernel for large shapes: 3 = auto by shape (default), 1 = 256x256 tile with staggered wave
+ *               groups (one workgroup per CU), 5 = the same kernel with 320x256 tiles, 0 = 128x128 generic kernel;
+ *   tn_variant: wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128;
+ *   tn_split_target: workgroups the wgrad token split aims for (default 512);
+ *   wgrad_group_chunks: token chunks per output tile of uvit_op_wgrad_group (0 = cost model, default). */
+typedef struct uvit_tuning { int32_t nt_variant, tn_variant, tn_split_target, wgrad_group_chunks; } uvit_tuning;
+void uvit_tuning_default(uvit_tuning* out);
+/* Replace the engine's tuning (values outside the lists above are refused with UVIT_ERR_ARG). */
+int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t);
 /* dual = 1 (default): teacher forward and the wgrad GEMMs run on an internal second HIP stream beside the
  * caller's stream; dual = 0: everything on the caller's stream (used to time one kernel in isolation).
  * Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
@@ -160,6 +166,7 @@ typedef struct uvit_gemm_epilogue {
     void* out; void* out2; const float* bias; const float* bias2; const float* gamma; const float* resid;
     const float* rowscale; const void* aux; const int64_t* mask; const float* mask_token;
     int32_t ldo, tokens, patches;
+    int32_t row0;   /* RESID: sample index of row m is (m + row0) / tokens */
 } uvit_gemm_epilogue;
 enum { UVIT_EPI_BF16 = 0, UVIT_EPI_QKV = 1, UVIT_EPI_GELU = 2, UVIT_EPI_RESID = 3, UVIT_EPI_F32 = 4,
        UVIT_EPI_PATCH = 5, UVIT_EPI_DGELU = 6, UVIT_EPI_QKV_ELU = 7,
@@ -170,9 +177,13 @@ enum { UVIT_EPI_BF16 = 0, UVIT_EPI_QKV = 1, UVIT_EPI_GELU = 2, UVIT_EPI_RESID = 
  * modeling_finetune.py:75-82,151,186 and the Conv2d-as-GEMM at :317 */
 int uvit_op_gemm_nt(int mode, const void* A_bf16, const void* W_bf16, int M, int N, int K, int lda, int ldw,
                     const uvit_gemm_epilogue* epi, uvit_stream stream);
-/* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64 */
+/* The same with explicit tuning (NULL = defaults); *tail_rows (nullable, host) receives the number of rows the
+ * launcher handed to its row-split tail launch (0 = single launch). */
+int uvit_op_gemm_nt_tuned(int mode, const void* A_bf16, const void* W_bf16, int M, int N, int K, int lda, int ldw,
+                          const uvit_gemm_epilogue* epi, const uvit_tuning* tune, int* tail_rows, uvit_stream stream);
+/* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64.  tune: NULL = defaults */
 int uvit_op_gemm_tn(const void* Y_bf16, const void* X_bf16, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
-                    uvit_stream stream);
+                    const uvit_tuning* tune, uvit_stream stream);
 /* All weight gradients of one layer's Linears in one launch (256x256 tiles, token-chunked, fp32 atomics into C).
  * Every problem: M % 64 == 0 and M >= 512, N % 256 == 0, K % 256 == 0; C (and the bias outputs) must hold zeros or a
  * value to add to.  bias (nullable) receives the column sums of Y[:, 0:bias_end) -- the Linear's bias gradient,
@@ -182,9 +193,7 @@ typedef struct uvit_wgrad_problem {
     const void* Y_bf16; const void* X_bf16; float* C; float* bias; float* bias2;
     int32_t bias_end, bias2_begin, M, N, K, ldy, ldx, ldc;
 } uvit_wgrad_problem;
-int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, uvit_stream stream);
-/* Tuning hook: token chunks per output tile in uvit_op_wgrad_group (0 = cost model, default). Process-wide. */
-int uvit_set_wgrad_group_chunks(int chunks);
+int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, const uvit_tuning* tune, uvit_stream stream);
 /* Attention core, modeling_finetune.py:152-185. qkv (B,N,3,H,64) bf16; biasP (H,NP,NP) f32 or NULL in the kernels'
  * private layout built by uvit_op_relpos_gather: bias * log2(e), -1e30 in padded key columns; lse is in log2 units */
 int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
@@ -218,6 +227,12 @@ int uvit_op_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, in
 /* F.smooth_l1_loss / F.mse_loss forward + gradient (engine_for_cyclical.py:147-150) */
 int uvit_op_smooth_l1(const float* out, const float* target, const int32_t* count_dev, float beta, int l2,
                       float loss_scale, float* loss, void* dout_bf16, int Mmax, int C, uvit_stream stream);
+/* WassersteinLoss forward + gradient (distloss.py:13-30, 73-79; engine_for_cyclical.py:152-161).  *loss += lam * loss_scale *
+ * sum_r softplus(u_r) / max softplus(u); dout_m_bf16 (which already holds the SmoothL1 gradient) is ADDED to, dout_c_bf16 is
+ * written.  scratch: 16 + Mmax floats.  Rows >= *count_dev are ignored (their dout_c rows are zeroed). */
+int uvit_op_wasserstein_loss(const float* out_m, const float* out_c, const float* tgt_m, const float* tgt_c,
+                             const int32_t* count_dev, float lam, float loss_scale, float* scratch, float* loss,
+                             void* dout_m_bf16, void* dout_c_bf16, int Mmax, int C, uvit_stream stream);
 /* target builder, engine_for_cyclical.py:92-122 */
 int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
                          int C, float eps, uvit_stream stream);

@@ -195,3 +195,98 @@ def test_two_stream_dropout_step_with_replayed_masks():
     assert st["loss"] == pytest.approx(ref.loss, rel=5e-3)
     assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)
     assert any(t is not None and (t == 0).any() for row in drop.path for t in row)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 5 at their real shapes ("Missing 1")
+# ------------------------------------------------------------------------------------------------
+def test_two_stream_vitb_forward_vs_golden(golden_dir):
+    """dist_beit_base_patch16_224's architecture (ViT-B/16 shape, 12 heads, 197 tokens), B=2: every layer of both
+    streams and both heads against the reference's own outputs (tests/golden/dist_vitb_spot.npz)."""
+    from gpu_util import native_model
+    fx = np.load(os.path.join(golden_dir, "dist_vitb_spot.npz"))
+    cfg = vo.VitConfig(init_values=0.1)
+    model, _ = native_model(cfg, two_stream=True)
+    assert sum(p.numel() for p in model.parameters()) == int(fx["n_params"]) == 115_778_640
+    model.eval()
+    x = closed_form_images("dvitb", 2, 224).cuda()
+    em, ec = model(x, None, True, layer_results="end")
+    for i in range(12):
+        check_entry(fx, f"mean_end{i}", em[i], 2e-2, 2e-2)
+        check_entry(fx, f"cov_end{i}", ec[i], 2e-2, 2e-2)
+    sm, sc = model(x, torch.from_numpy(fx["mask"]).cuda(), return_all_tokens=False)
+    check_entry(fx, "student_mean", sm, 2e-2, 2e-2)
+    check_entry(fx, "student_cov", sc, 2e-2, 2e-2)
+
+
+def test_two_stream_vitb_step_vs_golden_and_oracle(golden_dir):
+    """One full `--stochastic` step at the ViT-B/16 shape: loss and grad-norm against the REFERENCE's
+    train_one_epoch(stochastic=True) (fixture), every gradient tensor against the oracle (max-norm and relative-L2),
+    sampled gradients against the fixture, and the dead cov_qkv.weight (no gradient, never stepped)."""
+    from gpu_util import assert_grads_close, native_model, native_steps, native_trainer, oracle_state
+    fx = np.load(os.path.join(golden_dir, "dist_vitb_spot.npz"))
+    cfg = vo.VitConfig(init_values=0.1)
+    model, sd0 = native_model(cfg, two_stream=True)
+    ema, opt = native_trainer(model)
+    x = closed_form_images("dvitb", 2, 224)
+    mask = torch.from_numpy(fx["mask"])
+    tl = list(range(6, 12))
+    st = native_steps(model, ema, opt, [(x.cuda(), mask.cuda())], tl, stochastic=True, lam=1e-2)[0]
+    assert st["loss"] == pytest.approx(float(fx["step/loss"]), rel=5e-3)
+    assert st["grad_norm"] == pytest.approx(float(fx["step/grad_norm"]), rel=3e-2)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    gmax = max(float(np.abs(fx[k]).max()) for k in fx.files if k.startswith("grad0/") and k.endswith("/samples"))
+    for n in entries(fx, "grad0"):
+        check_entry(fx, "grad0/" + n, grads[n], 5e-2, 2e-2 * gmax, what="[dist ViT-B] ")
+        l2 = float(grads[n].double().norm())
+        assert l2 == pytest.approx(float(fx["grad0/" + n + "/l2"]), rel=3e-2, abs=1e-3 * float(fx["step/grad_norm"])), n
+    dead = fx["grad0_none"].tolist()
+    assert len(dead) == 12 and all(n.endswith("attn.cov_qkv.weight") for n in dead)
+    for n in dead:
+        assert grads[n].abs().sum() == 0 and torch.equal(model.state_dict()[n].cpu(), sd0[n])
+    p, e, m, v = oracle_state(sd0)
+    ref, loss_w, _, _ = vd.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=tuple(tl)), x, mask, 1, lam=1e-2)
+    assert ref.loss == pytest.approx(float(fx["step/loss"]), rel=1e-4)          # the oracle is pinned by the same fixture
+    print(f"two-stream ViT-B step: loss {st['loss']:.5f} (reference {float(fx['step/loss']):.5f}, Wasserstein term {loss_w:.5f})")
+    assert_grads_close(grads, ref.grads, what="[dist ViT-B] ")
+
+
+def test_two_stream_full_size_step_properties():
+    """BASELINE config 3: beit_base_patch16_224 --stochastic (the two-stream architecture) at bs=128 with attn-drop 0.05 /
+    drop-path 0.25: the same size-independent properties as the base model's full-size test, plus the frozen
+    cov_qkv.weight.  M = 2 x 25216 stacked rows: the fc1 / MULAUX GEMMs go through the row-split tail here."""
+    from gpu_util import full_size_step_properties
+    st = full_size_step_properties(vo.VitConfig(init_values=1e-4, drop_path_rate=0.25, attn_drop_rate=0.05),
+                                   vo.VitConfig(init_values=1e-4), B=128, img=224, n_patches=196, n_mask=120,
+                                   target_layers=list(range(6, 12)), two_stream=True, lam=1e-5, tag="dfull")
+    print("two-stream ViT-B bs=128 step:", {k: st[k] for k in ("loss", "grad_norm")})
+
+
+def test_two_stream_large_step_vs_oracle():
+    """dist_beit_large_patch16_224 (BASELINE config 5's architecture: embed 1024, depth 24, heads 16, two streams), B=1:
+    one full step against the oracle."""
+    from gpu_util import assert_grads_close, native_model, native_steps, native_trainer, oracle_state
+    from oracle.closed_form import exact_masks
+    cfg = vo.VitConfig(embed_dim=1024, depth=24, num_heads=16, init_values=0.1)
+    model, sd0 = native_model(cfg, two_stream=True)
+    assert sum(p.numel() for p in model.parameters()) == 406_762_944          # SURVEY 8d closed form
+    ema, opt = native_trainer(model)
+    x = closed_form_images("dvitl-step", 1, 224)
+    mask = exact_masks(1, 196, 120, 29)
+    tl = list(range(12, 24))
+    st = native_steps(model, ema, opt, [(x.cuda(), mask.cuda())], tl, stochastic=True, lam=1e-2)[0]
+    p, e, m, v = oracle_state(sd0)
+    ref, _, _, _ = vd.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=tuple(tl)), x, mask, 1, lam=1e-2)
+    assert st["loss"] == pytest.approx(ref.loss, rel=1e-2)
+    assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=5e-2)
+    grads = {n: q.grad for n, q in model.named_parameters()}
+    assert_grads_close(grads, ref.grads, max_tol=8e-2, l2_tol=3e-2, what="[dist ViT-L] ")
+
+
+def test_two_stream_large_bs64_step_properties():
+    """BASELINE config 5's per-GPU workload: dist_beit_large_patch16_224 at bs=64 (dropout on).  Property checks only."""
+    from gpu_util import full_size_step_properties
+    st = full_size_step_properties(vo.VitConfig(embed_dim=1024, depth=24, num_heads=16, init_values=1e-4, drop_path_rate=0.25, attn_drop_rate=0.05),
+                                   vo.VitConfig(embed_dim=1024, depth=24, num_heads=16, init_values=1e-4), B=64, img=224, n_patches=196,
+                                   n_mask=120, target_layers=list(range(12, 24)), two_stream=True, lam=1e-5, tag="dlfull")
+    print("two-stream ViT-L bs=64 step:", {k: st[k] for k in ("loss", "grad_norm")})

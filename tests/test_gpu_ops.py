@@ -39,6 +39,35 @@ def rnd(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).cuda()
 
 
+class tuned:
+    """Launch tuning for the GEMM calls inside the block.  It is an ARGUMENT of every call (uvit_tuning): the library
+    keeps no process-wide launcher state."""
+    cur = None
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        from uncertainty_vit_amd.native import Tuning
+        self.prev, tuned.cur = tuned.cur, Tuning.default(**self.kw)
+        return tuned.cur
+
+    def __exit__(self, *a):
+        tuned.cur = self.prev
+
+
+def _tune_ref():
+    return None if tuned.cur is None else C.byref(tuned.cur)
+
+
+def nt(L, mode, a, w, M, N, K, lda, ldw, ep, stream, tail=None):
+    return L.uvit_op_gemm_nt_tuned(mode, a, w, M, N, K, lda, ldw, ep, _tune_ref(), None if tail is None else C.byref(tail), stream)
+
+
+def tn(L, y, x, M, N, K, ldy, ldx, out, ldc, stream):
+    return tn(L, y, x, M, N, K, ldy, ldx, out, ldc, _tune_ref(), stream)
+
+
 def epi(**kw):
     from uncertainty_vit_amd.native import GemmEpilogue
     e = GemmEpilogue()
@@ -61,10 +90,10 @@ def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
     a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
     ref = a.float() @ w.float().t() + b
     out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    ok(L.uvit_op_gemm_nt(0, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, bias=b, ldo=N)), S()))
+    ok(nt(L, 0, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, bias=b, ldo=N)), S()))
     close(out, ref, what="bf16 out")
     out32 = torch.zeros(M, N, device="cuda")
-    ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+    ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
     close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
 
 
@@ -73,20 +102,17 @@ def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
 def test_gemm_nt_large_tile_kernel(L, M, N, K, variant):
     """Shapes that dispatch to the 256x256 deep-prefetch kernel (N % 256 == 0, M >= 1024): parity, a ragged
     last row tile, and a race screen (the counted-vmcnt pipeline must give bit-identical results every launch)."""
-    ok(L.uvit_set_gemm_variant(variant))
-    try:
+    with tuned(nt_variant=variant):
         a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
         ref = a.float() @ w.float().t() + b
         out32 = torch.zeros(M, N, device="cuda")
-        ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+        ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
         close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
         first = out32.clone()
         for _ in range(10):
             out32.zero_()
-            ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+            ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
             assert torch.equal(out32, first), "non-deterministic result: LDS pipeline race"
-    finally:
-        ok(L.uvit_set_gemm_variant(3))
 
 
 @pytest.mark.parametrize("variant", [0, 1, 5])
@@ -96,11 +122,8 @@ def test_gemm_nt_large_identity(L, variant):
     a = bf(torch.eye(K).repeat(M // K, 1).cuda())
     w = bf(((torch.arange(N * K).reshape(N, K) * 7) % 509 - 254).float().cuda() / 128)
     out = torch.zeros(M, N, device="cuda")
-    ok(L.uvit_set_gemm_variant(variant))
-    try:
-        ok(L.uvit_op_gemm_nt(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, ldo=N)), S()))
-    finally:
-        ok(L.uvit_set_gemm_variant(3))
+    with tuned(nt_variant=variant):
+        ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, ldo=N)), S()))
     torch.testing.assert_close(out, w.float().t().repeat(M // K, 1).contiguous(), rtol=0, atol=0)
 
 
@@ -110,18 +133,15 @@ def test_gemm_nt_asymmetric_identity(L):
     a = bf(torch.eye(K).cuda())
     w = bf((torch.arange(192 * K).reshape(192, K) % 251 - 125).float().cuda() / 64)
     out = torch.zeros(K, 192, device="cuda")
-    ok(L.uvit_op_gemm_nt(4, P(a), P(w), K, 192, K, K, K, C.byref(epi(out=out, ldo=192)), S()))
+    ok(nt(L, 4, P(a), P(w), K, 192, K, K, K, C.byref(epi(out=out, ldo=192)), S()))
     torch.testing.assert_close(out, w.float().t().contiguous(), rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("variant,nb,tokens,Cd,Pn", [(3, 3, 10, 128, 9), (0, 11, 100, 256, 140), (1, 11, 100, 256, 140), (5, 11, 100, 256, 140)])
 def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L, variant, nb, tokens, Cd, Pn):
     """Every fused epilogue, on the 128x128 kernel (small shapes) and on each large-tile variant (ragged M = 1100)."""
-    ok(L.uvit_set_gemm_variant(variant))
-    try:
+    with tuned(nt_variant=variant):
         _epilogue_modes(L, nb, tokens, Cd, Pn)
-    finally:
-        ok(L.uvit_set_gemm_variant(3))
 
 
 def test_gemm_nt_row_split_of_a_nearly_empty_last_round(L):
@@ -133,7 +153,7 @@ def test_gemm_nt_row_split_of_a_nearly_empty_last_round(L):
     b2, gam, res = rnd(N, seed=3), rnd(N, scale=0.1, seed=4), rnd(M, N, seed=5)
     dp = (torch.arange(B, device="cuda") % 3).float() * 0.625
     xo = torch.zeros(M, N, device="cuda"); branch = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    ok(L.uvit_op_gemm_nt(3, P(a), P(w), M, N, K, K, K,
+    ok(nt(L, 3, P(a), P(w), M, N, K, K, K,
                          C.byref(epi(out=xo, out2=branch, bias=b2, gamma=gam, resid=res, rowscale=dp, ldo=N, tokens=tokens)), S()))
     y = a.float() @ w.float().t() + b2
     close(branch, y, what="resid branch")
@@ -146,18 +166,18 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
     # QKV: bias = cat(q_bias, 0, v_bias)
     w = bf(rnd(3 * Cd, Cd, scale=0.05, seed=5)); qb, vb = rnd(Cd, seed=6), rnd(Cd, seed=7)
     out = torch.zeros(M, 3 * Cd, dtype=torch.bfloat16, device="cuda")
-    ok(L.uvit_op_gemm_nt(1, P(x), P(w), M, 3 * Cd, Cd, Cd, Cd, C.byref(epi(out=out, bias=qb, bias2=vb, ldo=3 * Cd)), S()))
+    ok(nt(L, 1, P(x), P(w), M, 3 * Cd, Cd, Cd, Cd, C.byref(epi(out=out, bias=qb, bias2=vb, ldo=3 * Cd)), S()))
     close(out, x.float() @ w.float().t() + torch.cat([qb, torch.zeros_like(vb), vb]), what="qkv")
     # GELU: a = gelu(h), h kept
     w1 = bf(rnd(Hd, Cd, scale=0.1, seed=8)); b1 = rnd(Hd, seed=9)
     a_out = torch.zeros(M, Hd, dtype=torch.bfloat16, device="cuda"); h_out = torch.zeros_like(a_out)
-    ok(L.uvit_op_gemm_nt(2, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a_out, out2=h_out, bias=b1, ldo=Hd)), S()))
+    ok(nt(L, 2, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a_out, out2=h_out, bias=b1, ldo=Hd)), S()))
     h_ref = x.float() @ w1.float().t() + b1
     close(h_out, h_ref, what="gelu h")
     close(a_out, F.gelu(h_out.float()), rtol=1e-2, atol=1e-2, what="gelu a")
     # GELU_DG / MULAUX: the training pair -- gelu(h) with gelu'(h) stored, then dH = (dY @ W2) * gelu'(h)
     a2 = torch.zeros_like(a_out); dg = torch.zeros_like(a_out)
-    ok(L.uvit_op_gemm_nt(8, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a2, out2=dg, bias=b1, ldo=Hd)), S()))
+    ok(nt(L, 8, P(x), P(w1), M, Hd, Cd, Cd, Cd, C.byref(epi(out=a2, out2=dg, bias=b1, ldo=Hd)), S()))
     assert torch.equal(a2, a_out)
     hq = h_out.float().requires_grad_(True)
     F.gelu(hq).sum().backward()
@@ -166,7 +186,7 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
     w2 = bf(rnd(Cd, Hd, scale=0.05, seed=10)); b2, gam = rnd(Cd, seed=11), rnd(Cd, scale=0.1, seed=12)
     res = rnd(M, Cd, seed=13); dp = torch.tensor([0.0] + [1.25] * (nb - 1), device="cuda")
     xo = torch.zeros(M, Cd, device="cuda"); branch = torch.zeros(M, Cd, dtype=torch.bfloat16, device="cuda")
-    ok(L.uvit_op_gemm_nt(3, P(a_out), P(w2), M, Cd, Hd, Hd, Hd,
+    ok(nt(L, 3, P(a_out), P(w2), M, Cd, Hd, Hd, Hd,
                          C.byref(epi(out=xo, out2=branch, bias=b2, gamma=gam, resid=res, rowscale=dp, ldo=Cd, tokens=tokens)), S()))
     y = a_out.float() @ w2.float().t() + b2
     close(branch, y, what="resid branch")
@@ -174,19 +194,19 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
     # DGELU: dH = (dY @ W2) * gelu'(h)
     dy = bf(rnd(M, Cd, scale=0.1, seed=14)); w2t = bf(w2.float().t())
     dh = torch.zeros(M, Hd, dtype=torch.bfloat16, device="cuda")
-    ok(L.uvit_op_gemm_nt(6, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh, aux=h_out, ldo=Hd)), S()))
+    ok(nt(L, 6, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh, aux=h_out, ldo=Hd)), S()))
     hh = h_out.float().requires_grad_(True)
     F.gelu(hh).backward(dy.float() @ w2.float())
     close(dh, hh.grad, rtol=2e-2, atol=5e-3, what="dgelu")
     dh2 = torch.zeros_like(dh)
-    ok(L.uvit_op_gemm_nt(9, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh2, aux=dg, ldo=Hd)), S()))
+    ok(nt(L, 9, P(dy), P(w2t), M, Hd, Cd, Cd, Cd, C.byref(epi(out=dh2, aux=dg, ldo=Hd)), S()))
     close(dh2, hh.grad, rtol=2e-2, atol=8e-3, what="mul-aux dgelu")
     # PATCH: rows b*P+p -> token rows b*(P+1)+1+p, masked rows take the mask token
     B, Kpe = nb - 3 if nb > 3 else 3, 768
     cols = bf(rnd(B * Pn, Kpe, seed=15)); wpe = bf(rnd(Cd, Kpe, scale=0.03, seed=16)); bpe = rnd(Cd, seed=17)
     mt = rnd(Cd, seed=18); mask = (torch.arange(B * Pn, device="cuda") % 3 == 0).long()
     x0 = torch.full((B * (Pn + 1), Cd), 7.0, device="cuda")
-    ok(L.uvit_op_gemm_nt(5, P(cols), P(wpe), B * Pn, Cd, Kpe, Kpe, Kpe,
+    ok(nt(L, 5, P(cols), P(wpe), B * Pn, Cd, Kpe, Kpe, Kpe,
                          C.byref(epi(out=x0, bias=bpe, mask=mask, mask_token=mt, ldo=Cd, patches=Pn)), S()))
     ref = cols.float() @ wpe.float().t() + bpe
     ref = torch.where(mask[:, None].bool(), mt[None, :].expand_as(ref), ref).view(B, Pn, Cd)
@@ -199,7 +219,7 @@ def _epilogue_modes(L, nb, tokens, Cd, Pn):
 def test_gemm_tn_wgrad(L, M, N, K):
     y, x = bf(rnd(M, N, scale=0.1, seed=20)), bf(rnd(M, K, seed=21))
     out = torch.zeros(N, K, device="cuda")
-    ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+    ok(tn(L, P(y), P(x), M, N, K, N, K, P(out), K, S()))
     ref = y.float().t() @ x.float()
     close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M / 64), what="wgrad")
 
@@ -208,21 +228,18 @@ def test_gemm_tn_wgrad(L, M, N, K):
 def test_gemm_tn_wgrad_256_tile_kernel(L, M, N, K):
     """The 256x256 staggered wgrad kernel: split reductions (fp32 atomics), the no-split store path (M = 512),
     odd K-tile counts, and a race screen on a shape without atomics (bit-identical every launch)."""
-    ok(L.uvit_set_tn_variant(1))
-    try:
+    with tuned(tn_variant=1):
         y, x = bf(rnd(M, N, scale=0.1, seed=20)), bf(rnd(M, K, seed=21))
         ref = y.float().t() @ x.float()
         out = torch.zeros(N, K, device="cuda")
-        ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+        ok(tn(L, P(y), P(x), M, N, K, N, K, P(out), K, S()))
         close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(M / 64), what="wgrad 256")
         if M == 512:
             first = out.clone()
             for _ in range(10):
                 out.fill_(7.0)     # the no-split path overwrites
-                ok(L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()))
+                ok(tn(L, P(y), P(x), M, N, K, N, K, P(out), K, S()))
                 assert torch.equal(out, first), "non-deterministic result: LDS pipeline race"
-    finally:
-        ok(L.uvit_set_tn_variant(3))
 
 
 @pytest.mark.parametrize("chunks", [0, 1, 3])
@@ -245,11 +262,8 @@ def test_wgrad_group_with_fused_bias_sums(L, chunks):
         q.bias_end, q.bias2_begin = (n if bias == "full" else Cd), 2 * Cd
         q.M, q.N, q.K, q.ldy, q.ldx, q.ldc = m, n, k, n, k, k
         refs.append((y.float().t() @ x.float() + 0.5, y.float().sum(0)))
-    ok(L.uvit_set_wgrad_group_chunks(chunks))
-    try:
-        ok(L.uvit_op_wgrad_group(probs, len(specs), S()))
-    finally:
-        ok(L.uvit_set_wgrad_group_chunks(0))
+    with tuned(wgrad_group_chunks=chunks) as tu:
+        ok(L.uvit_op_wgrad_group(probs, len(specs), C.byref(tu), S()))
     for (y, x, out, b1, b2), (ref, colsum), (m, n, k, bias) in zip(keep, refs, specs):
         close(out, ref, rtol=2e-3, atol=2e-3 * math.sqrt(m / 64), what="grouped wgrad")
         if bias == "full":
@@ -259,7 +273,7 @@ def test_wgrad_group_with_fused_bias_sums(L, chunks):
             close(b2, colsum[2 * Cd:], rtol=2e-3, atol=2e-2, what="v bias sums")
     # a problem that does not qualify is refused, not approximated
     probs[0].N = 3 * Cd - 8
-    assert L.uvit_op_wgrad_group(probs, len(specs), S()) == -2
+    assert L.uvit_op_wgrad_group(probs, len(specs), None, S()) == -2
 
 
 def test_gemm_tn_256_tile_identity(L):
@@ -269,11 +283,8 @@ def test_gemm_tn_256_tile_identity(L):
     x = ((torch.arange(M * K).reshape(M, K) * 5 % 251) - 125).float().cuda() / 64
     out = torch.zeros(N, K, device="cuda")
     yb, xb = bf(y), bf(x)
-    ok(L.uvit_set_tn_variant(1))
-    try:
-        ok(L.uvit_op_gemm_tn(P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
-    finally:
-        ok(L.uvit_set_tn_variant(3))
+    with tuned(tn_variant=1):
+        ok(tn(L, P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
     torch.testing.assert_close(out, xb.float(), rtol=0, atol=0)
 
 
@@ -283,7 +294,7 @@ def test_gemm_tn_asymmetric(L):
     x = ((torch.arange(M * K).reshape(M, K) % 127) - 63).float().cuda() / 32
     out = torch.zeros(N, K, device="cuda")
     yb, xb = bf(y), bf(x)          # keep the operands alive across the asynchronous launch
-    ok(L.uvit_op_gemm_tn(P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
+    ok(tn(L, P(yb), P(xb), M, N, K, N, K, P(out), K, S()))
     ref = torch.zeros(N, K, device="cuda"); ref[:M] = xb.float()
     torch.testing.assert_close(out, ref, rtol=0, atol=0)
 
@@ -496,3 +507,132 @@ def test_mask_compact_im2col_targets_droppath(L):
     for i in range(4):
         for br, ref in ((0, p1[i]), (1, p2[i])):
             torch.testing.assert_close(sc[i, br], torch.ones(7) if ref is None else ref, rtol=1e-6, atol=0)
+
+
+def test_gemm_nt_row_split_tail_branch_two_stream_shapes(L):
+    """The row-split tail of the auto dispatch at the shape that reaches it in the benchmarked two-stream bs=128 step
+    (stacked mean + covariance rows, M = 2 x 25216; N = 3072, K = 768: 2364 tiles of 256x256 = 9 rounds of 256 CUs + 60, so
+    the last 1280 rows go to the 128x128 kernel with out / out2 / aux / resid / row0 moved by hand): GELU_DG (out + out2),
+    MULAUX (aux) and RESID (resid + per-sample drop-path through row0).  The launcher reports the tail rows; the test
+    asserts the branch was really taken."""
+    tokens, B = 197, 256
+    M, N, K = B * tokens, 3072, 768
+    x = bf(rnd(M, K, seed=1)); w = bf(rnd(N, K, scale=0.05, seed=2)); b = rnd(N, seed=3)
+    a_out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda"); dg = torch.zeros_like(a_out)
+    tail = C.c_int(0)
+    ok(nt(L, 8, P(x), P(w), M, N, K, K, K, C.byref(epi(out=a_out, out2=dg, bias=b, ldo=N)), S(), tail=tail))
+    assert tail.value > 0 and tail.value % 256 == 0, f"row-split tail not taken (tail rows {tail.value}); CU count != 256?"
+    t0 = M - tail.value
+    for lo, hi in ((0, 4096), (t0 - 2048, t0 + 2048), (M - 2048, M)):      # head, the seam, the end of the tail
+        h = (x[lo:hi].float() @ w.float().t() + b).to(torch.bfloat16).float().requires_grad_(True)
+        F.gelu(h).sum().backward()
+        close(a_out[lo:hi], F.gelu(h.detach()), rtol=1e-2, atol=1e-2, what=f"gelu rows {lo}:{hi}")
+        close(dg[lo:hi], h.grad, rtol=1e-2, atol=1e-2, what=f"gelu' rows {lo}:{hi}")
+    # MULAUX: dH = (dY @ W2) * aux
+    dy = bf(rnd(M, K, scale=0.1, seed=4)); dh = torch.zeros_like(a_out)
+    tail2 = C.c_int(0)
+    ok(nt(L, 9, P(dy), P(w), M, N, K, K, K, C.byref(epi(out=dh, aux=dg, ldo=N)), S(), tail=tail2))
+    assert tail2.value == tail.value
+    for lo, hi in ((t0 - 1024, t0 + 1024), (M - 1024, M)):
+        close(dh[lo:hi], (dy[lo:hi].float() @ w.float().t()) * dg[lo:hi].float(), rtol=2e-2, atol=8e-3, what=f"mulaux rows {lo}:{hi}")
+    del dh, dg
+    # RESID: x + dp[sample] * gamma * (acc + bias), the sample index of the tail rows comes through row0
+    gam, res = rnd(N, scale=0.1, seed=5), rnd(M, N, seed=6)
+    dp = ((torch.arange(B, device="cuda") % 4).float() * 0.5)
+    xo = torch.zeros(M, N, device="cuda"); branch = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    tail3 = C.c_int(0)
+    ok(nt(L, 3, P(x), P(w), M, N, K, K, K,
+          C.byref(epi(out=xo, out2=branch, bias=b, gamma=gam, resid=res, rowscale=dp, ldo=N, tokens=tokens)), S(), tail=tail3))
+    assert tail3.value == tail.value
+    for lo, hi in ((t0 - 1024, t0 + 1024), (M - 1024, M)):
+        y = x[lo:hi].float() @ w.float().t() + b
+        close(branch[lo:hi], y, what=f"resid branch rows {lo}:{hi}")
+        scale = dp[torch.arange(lo, hi, device="cuda") // tokens][:, None]
+        close(xo[lo:hi], res[lo:hi] + scale * gam * y, rtol=5e-3, atol=5e-3, what=f"resid out rows {lo}:{hi}")
+
+
+def test_gemm_two_host_threads_two_streams_different_tuning(L):
+    """include/uvit.h: no mutable process-wide launcher state.  Two host threads launch NT GEMMs on their own HIP streams
+    with DIFFERENT tuning (one forces the 128x128 kernel, one the auto dispatch with its row-split tail) at the same time;
+    every result must equal the single-threaded result of the same tuning bit for bit."""
+    import threading
+    from uncertainty_vit_amd.native import Tuning
+    M, N, K = 197 * 128, 768, 2048                       # auto dispatch: 320-row tiles; variant 1: 256-row tiles + tail
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
+    tunes = [Tuning.default(nt_variant=0), Tuning.default(nt_variant=1)]
+
+    def run(tu, out, stream):
+        return L.uvit_op_gemm_nt_tuned(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out, bias=b, ldo=N)), C.byref(tu), None,
+                                       C.c_void_p(stream.cuda_stream))
+    refs = []
+    for tu in tunes:
+        o = torch.zeros(M, N, device="cuda")
+        ok(run(tu, o, torch.cuda.current_stream()))
+        refs.append(o)
+    torch.cuda.synchronize()
+    close(refs[0], a.float() @ w.float().t() + b, rtol=2e-3, atol=2e-3, what="variant 0")
+    close(refs[1], refs[0], rtol=1e-4, atol=1e-4, what="variant 1 vs 0")
+    errs = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            outs = [torch.zeros(M, N, device="cuda") for _ in range(4)]
+            torch.cuda.synchronize()
+            for it in range(40):
+                rc = run(tunes[i], outs[it % 4], st)
+                if rc != 0:
+                    errs.append((i, it, rc)); return
+            st.synchronize()
+            for o in outs:
+                if not torch.equal(o, refs[i]):
+                    errs.append((i, "mismatch", float((o - refs[i]).abs().max())))
+        except Exception as ex:      # noqa: BLE001
+            errs.append((i, repr(ex)))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("Mrows,count,Cd", [(40, 40, 128), (300, 257, 768), (15360, 15360, 768)])
+def test_wasserstein_loss_operator(L, Mrows, count, Cd):
+    """WassersteinLoss (distloss.py:13-30 with wasserstein_distance :73-79) as an operator: value and the gradients with
+    respect to the mean and covariance outputs, including the NON-LOCAL gradient of the arg-max row (`pos / pos.abs().max()`
+    routes -sum_s g'(u_s) u_s / m to it), against an fp32 autograd restatement on the same inputs.  Rows >= count are padding."""
+    lam, ls = 1e-2, 1.0
+    om, oc = rnd(Mrows, Cd, seed=1), rnd(Mrows, Cd, seed=2)
+    tm, tc = rnd(Mrows, Cd, seed=3), rnd(Mrows, Cd, seed=4)
+    om[min(7, count - 1)] *= 3.0                         # a clear arg-max row that is not row 0
+    cnt = torch.tensor([count], dtype=torch.int32, device="cuda")
+    base = torch.zeros(Mrows, Cd, dtype=torch.bfloat16, device="cuda")   # the SmoothL1 gradient already in dout_m: the
+    base[1, 5] = 1.0                                                         # operator ADDS to it (checked on one element)
+    dm = base.clone(); dc = torch.full((Mrows, Cd), 9.0, dtype=torch.bfloat16, device="cuda")
+    scratch = torch.zeros(16 + Mrows, device="cuda"); loss = torch.full((1,), 0.25, device="cuda")
+    ok(L.uvit_op_wasserstein_loss(P(om), P(oc), P(tm), P(tc), P(cnt), lam, ls, P(scratch), P(loss), P(dm), P(dc), Mrows, Cd, S()))
+
+    a, c = om[:count].clone().requires_grad_(True), oc[:count].clone().requires_grad_(True)
+    mo, co, mt, ct = torch.sigmoid(a), torch.sigmoid(c), torch.sigmoid(tm[:count]), torch.sigmoid(tc[:count])
+    pos = ((mo - mt) ** 2).sum(-1) + ((torch.sqrt(co.clamp(min=1e-24)) - torch.sqrt(ct.clamp(min=1e-24))) ** 2).sum(-1)
+    pos = pos / pos.abs().max()
+    lo = -torch.log(torch.sigmoid(-pos + 1e-24))
+    lo = lo / lo.abs().max()
+    ref = lo.sum() * lam
+    ref.backward()
+    assert loss.item() - 0.25 == pytest.approx(ref.item(), rel=2e-4)
+    assert dm[1, 5].item() == pytest.approx(1.0, abs=8e-3)
+    dm[1, 5] = dm[1, 4]; a.grad[1, 5] = a.grad[1, 4]     # exclude the marker from the precision check
+    gm = dm[:count].float()
+    amax = int(pos.argmax())
+    gmax = a.grad.abs().max().item()
+    close(gm, a.grad, rtol=1e-2, atol=1e-2 * gmax, what="d mean_out")
+    close(dc[:count], c.grad, rtol=1e-2, atol=1e-2 * c.grad.abs().max().item(), what="d cov_out")
+    rel = (gm[amax] - a.grad[amax]).norm() / a.grad[amax].norm()
+    assert rel < 2e-2, f"arg-max row {amax}: relative L2 error {rel}"
+    others = torch.arange(count, device="cuda") != amax
+    rel_o = (gm[others] - a.grad[others]).norm() / a.grad[others].norm()
+    assert rel_o < 2e-2, f"other rows: relative L2 error {rel_o}"
+    if count < Mrows:
+        assert torch.all(dc[count:] == 0) and torch.all(dm[count:] == 0)

@@ -192,6 +192,14 @@ for l in range(m.depth - 1, -1, -1):
 red.reduce(g, red.head_range); red.reduce(g, red.embed_range); red.reduce(g, red.small_range)
 red.finish()
 assert torch.all(g == 3.0), "every gradient element must be summed over the 2 ranks exactly once"
+# bf16 buckets (SURVEY 8e: 164.5 MB on the wire instead of 329 MB): same tiling, values rounded to bf16 once per rank
+red16 = GradReducer(m, True, comm_dtype=torch.bfloat16)
+g16 = torch.full_like(m._arena, 1.0 + 2.0 ** -10) * float(rank + 1)      # 1 + 2^-10 is not a bf16 number
+for l in range(m.depth - 1, -1, -1):
+    red16.reduce(g16, red16.layer_ranges[l])
+red16.reduce(g16, red16.head_range); red16.reduce(g16, red16.embed_range); red16.reduce(g16, red16.small_range)
+red16.finish()
+assert g16.dtype == torch.float32 and torch.all(g16 == 3.0), "bf16 wire: round(1+2^-10) + round(2+2^-9) = 3, widened back to fp32"
 hp = make_step_params([1], ArenaAdamW(m, 1e-3, 0.05), 3.0, 2.0, False, -1, True, True, 0.9998, True, utils.get_world_size(), 0, 0)
 assert abs(hp.grad_scale - 0.5) < 1e-9          # SUM all-reduce then 1/world == DDP's mean
 sv = utils.SmoothedValue(); sv.update(float(rank + 1)); sv.synchronize_between_processes()
@@ -224,6 +232,9 @@ def test_blockwise_mask_generator_matches_reference(golden_dir):
             got = np.stack([g() for _ in range(4)])
             assert got.dtype == np.int64 and np.array_equal(got, fx[f"{name}{seed}"]), (name, seed)
             assert (got.sum(axis=(1, 2)) <= n).all() and got.max() <= 1        # at most n ones
+            # the batched call (one per step in the loader) consumes the same stream: identical masks
+            gb = MaskingGenerator(size, n, min_num_patches=mn, max_num_patches=mx, seed=1000 * seed + 7)
+            assert np.array_equal(gb.batch(4), fx[f"{name}{seed}"]), (name, seed, "batch")
 
 
 def test_device_prefetcher_passes_batches_through_in_order():
@@ -235,3 +246,41 @@ def test_device_prefetcher_passes_batches_through_in_order():
     assert [lbl for _, lbl in got] == list(range(5))
     assert all(s.dtype == torch.float32 and float(s[0, 0, 0, 0]) == i for i, ((s, _), _) in enumerate(got))
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def test_bench_self_launch_command_and_clean_failure_without_gpus():
+    """`python bench.py --gpus N` must work when invoked directly: it builds a torch.distributed.run
+    command for N ranks on 127.0.0.1 before touching the GPU, and on a machine with fewer GPUs it exits 2 with a message
+    instead of tripping an assert."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launch_command(4, 29777, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29777" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.samefile(cmd[cmd.index("--master-port") + 2], os.path.join(ROOT, "bench.py"))
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 2 and "needs 2 visible GPUs" in r.stderr and "AssertionError" not in r.stderr, r.stderr[-800:]
+        # a launcher whose world size disagrees with --gpus is refused the same way
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                           capture_output=True, text=True, timeout=240)
+        assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_target_layers_follow_python_list_indexing(native):
+    """`[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): negative indices count from the last block,
+    out-of-range raises IndexError, a repeated index is kept (it is averaged twice, the divisor is len(target_layers))."""
+    from uncertainty_vit_amd.engine_for_cyclical import make_step_params
+    from uncertainty_vit_amd.optim_factory import ArenaAdamW
+    opt = ArenaAdamW(tiny_model(), 1e-3, 0.05)
+    mk = lambda tl: make_step_params(tl, opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, 1, 0, 0, depth=12)  # noqa: E731
+    hp = mk([-1, 10, 10, -12])
+    assert hp.n_target_layers == 4 and list(hp.target_layers[:4]) == [11, 10, 10, 0]
+    for bad in ([12], [-13], [6, 7, 99]):
+        with pytest.raises(IndexError):
+            mk(bad)

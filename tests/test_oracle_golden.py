@@ -165,3 +165,51 @@ def test_two_stream_model_and_step(golden_dir):
         check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)
     for n in entries(fx, "ema"):
         check_entry(fx, "ema/" + n, ema[n], 1e-5, 1e-7)
+
+
+def test_two_stream_vitb_shape_spot(golden_dir):
+    """The two-stream oracle at the ViT-B/16 shape (12 heads, 197 tokens; BASELINE config 3's architecture): forward of
+    both streams, and one stochastic=True step (loss, grad-norm, gradients) against the reference's own outputs."""
+    from oracle import vit_oracle_dist as vd
+    fx = np.load(os.path.join(golden_dir, "dist_vitb_spot.npz"))
+    cfg = vo.VitConfig(init_values=0.1)
+    p = closed_form_state(vd.param_shapes(cfg), gamma=0.1)
+    assert sum(t.numel() for t in p.values()) == int(fx["n_params"])
+    x = closed_form_images("dvitb", 2, 224)
+    mask = torch.from_numpy(fx["mask"])
+    em, ec = vd.forward(p, cfg, x, None, True, "end")
+    for i in range(12):
+        check_entry(fx, f"mean_end{i}", em[i], 5e-4, 5e-6)
+        check_entry(fx, f"cov_end{i}", ec[i], 5e-4, 5e-6)
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    res, lw, _, _ = vd.train_step(p, ema, m, v, cfg, vo.StepHParams(target_layers=tuple(range(6, 12))), x, mask, 1, lam=1e-2)
+    assert res.loss == pytest.approx(float(fx["step/loss"]), rel=2e-4)
+    assert res.grad_norm == pytest.approx(float(fx["step/grad_norm"]), rel=2e-3)
+    assert set(fx["grad0_none"].tolist()) == {f"blocks.{i}.attn.cov_qkv.weight" for i in range(12)}
+    gmax = max(float(np.abs(fx[k]).max()) for k in fx.files if k.startswith("grad0/") and k.endswith("/samples"))
+    for n in entries(fx, "grad0"):
+        check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 1e-5 * gmax)
+        assert float(res.grads[n].double().norm()) == pytest.approx(float(fx["grad0/" + n + "/l2"]), rel=2e-3, abs=1e-6), n
+
+
+def test_loss_curve_vitb_first_steps(golden_dir):
+    """The ViT-B/16 loss-curve fixture (reference train_one_epoch, 100 steps): the oracle follows its first 12 steps --
+    the fast-moving part of the curve -- to fp32 round-off (the whole curve is the GPU test's job; 100 ViT-B steps on
+    the host cores would not fit the CPU suite's budget)."""
+    fx = np.load(os.path.join(golden_dir, "loss_curve_vitb.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    assert (img, dim, depth, heads, steps) == (224, 768, 12, 12, 100)
+    cfg = vo.VitConfig(init_values=0.1)
+    p = closed_form_state(vo.param_shapes(cfg), gamma=0.1)
+    hp = vo.StepHParams(target_layers=tuple(range(6, 12)), lr=float(fx["lr"]))
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    fixed = [(closed_form_images(f"curveB/{s}", B, img), torch.from_numpy(fx[f"mask{s}"])) for s in range(4)]
+    for s in range(4):
+        assert torch.equal(fixed[s][1], exact_masks(B, 196, n_mask, 500 + s))
+    losses = [vo.train_step(p, ema, m, v, cfg, hp, *fixed[s % 4], s + 1).loss for s in range(12)]
+    np.testing.assert_allclose(np.array(losses), fx["loss"][:12], atol=2e-4, rtol=0)
+    assert fx["loss"][0] - fx["loss"][-1] > 0.1          # the curve really moves: 0.40 -> 0.24

@@ -194,6 +194,70 @@ def gen_loss_curve(mc, eng):
     print("wrote loss curve", rec["loss"][:3], "...", rec["loss"][-3:])
 
 
+def gen_loss_curve_vitb(mc, eng):
+    """north_star's loss-curve criterion at the ViT-B/16 shape it is stated for: the reference's train_one_epoch,
+    base model, B=2, dropout 0, four fixed batches cycled for 100 steps, constant lr (SURVEY 8c G5 "base config")."""
+    B, n_mask = 2, 120
+    model = build(mc, 224, 768, 12, 12, 0.1)
+    fixed = [(closed_form_images(f"curveB/{s}", B, 224), exact_masks(B, 196, n_mask, 500 + s)) for s in range(4)]
+    batches = [fixed[s % 4] for s in range(100)]
+    model.train()
+    rec, _, _, _ = run_reference_steps(eng, model, batches, list(range(6, 12)), lr=CURVE_LR)
+    out = {"cfg": np.array([224, 768, 12, 12, B, n_mask, 100], dtype=np.int64),
+           "loss": np.array(rec["loss"]), "grad_norm": np.array(rec["grad_norm"]), "lr": np.float64(CURVE_LR)}
+    for s, (_, bm) in enumerate(fixed):
+        out[f"mask{s}"] = bm.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss_curve_vitb.npz"), **out)
+    print("wrote ViT-B loss curve", rec["loss"][:3], "...", rec["loss"][-3:])
+
+
+def gen_dist_vitb_spot(mc, eng):
+    """Two-stream model at the ViT-B shape (BASELINE config 3's architecture), B=2, closed-form weights: per-layer
+    checksums + samples of both streams, the student heads, and ONE reference train_one_epoch(stochastic=True) step
+    (loss, grad-norm, gradients of blocks 0 / 11 and the non-block parameters, names of the gradient-less tensors)."""
+    import modeling_cyclical_dist as mcd
+    import optim_factory
+    import timm.utils as U
+    model = mcd.DistVisionTransformerForCyclicalTraining(
+        img_size=224, patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.1, use_shared_rel_pos_bias=True,
+        use_abs_pos_emb=False, drop_path_rate=0.0, attn_drop_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype == torch.float32}
+    model.load_state_dict(closed_form_state(shapes, gamma=0.1), strict=False)
+    B = 2
+    x = closed_form_images("dvitb", B, 224)
+    mask = exact_masks(B, 196, 120, 13)
+    out = {"mask": mask.numpy(), "n_params": np.int64(sum(p.numel() for p in model.parameters()))}
+    model.eval()
+    with torch.no_grad():
+        em, ec = model(x, None, True, layer_results="end")
+        sm, sc = model(x, mask, return_all_tokens=False)
+    for i in range(12):
+        put(out, f"mean_end{i}", em[i])
+        put(out, f"cov_end{i}", ec[i])
+    put(out, "student_mean", sm)
+    put(out, "student_cov", sc)
+    model.train()
+    ema = U.ModelEmaV2(model, decay=0.9998)
+    args = SimpleNamespace(opt="adamw", lr=2e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+    opt = optim_factory.create_optimizer(args, model)
+    scaler = ref_harness.HarnessScaler()
+    st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, list(range(6, 12)), [((x, mask), torch.zeros(1))], opt,
+                             torch.device("cpu"), 0, scaler, max_norm=3.0, l1_beta=2.0, start_steps=0, layer_results="end",
+                             loss_scale=-1, target_layer_norm_last=True, post_target_layer_norm=True, stochastic=True,
+                             lambda_pretraining=1e-2)
+    out["step/loss"], out["step/grad_norm"] = np.float64(st["loss"]), np.float64(float(st["grad_norm"]))
+    pn = [n for n, _ in model.named_parameters()]
+    out["grad0_none"] = np.array([n for n, g in zip(pn, scaler.grads) if g is None])
+    for n, g in zip(pn, scaler.grads):
+        if g is None or (n.startswith("blocks.") and not (n.startswith("blocks.0.") or n.startswith("blocks.11."))):
+            continue
+        put(out, "grad0/" + n, g)
+        out["grad0/" + n + "/l2"] = np.float64(g.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "dist_vitb_spot.npz"), **out)
+    print("wrote dist vitb spot; loss", st["loss"], "gnorm", float(st["grad_norm"]))
+
+
 def gen_vitb_spot(mc):
     """ViT-B shape, B=2, closed-form weights: per-layer checksums + samples, and gradients of
     smooth_l1(student, 0) for blocks 0 and 11 and the non-block parameters."""
@@ -287,6 +351,10 @@ def main():
         gen_loss_curve(mc, eng)
     if a.only in (None, "vitb"):
         gen_vitb_spot(mc)
+    if a.only in (None, "dvitb"):
+        gen_dist_vitb_spot(mc, eng)
+    if a.only in (None, "curveB"):
+        gen_loss_curve_vitb(mc, eng)
     if a.only in (None, "sched"):
         gen_schedules()
     if a.only in (None, "masks"):

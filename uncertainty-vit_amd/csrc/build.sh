@@ -4,6 +4,10 @@ set -e
 cd "$(dirname "$0")"
 OUT=${1:-../libuvit.so}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wall -Wno-unused-function"
+# Fingerprint of the sources this library is built from: native.lib() recomputes it and refuses a stale .so
+# (struct layouts in include/uvit.h travel by value through ctypes).
+HASH=$(cat $(ls *.hip *.h | LC_ALL=C sort) ../../include/uvit.h | sha256sum | cut -c1-16)
+FLAGS="$FLAGS -DUVIT_SRC_HASH=\"$HASH\""
 mkdir -p obj
 pids=()
 for f in gemm attention attention2 norm elementwise optim engine; do
@@ -12,4 +16,5 @@ for f in gemm attention attention2 norm elementwise optim engine; do
 done
 for p in "${pids[@]}"; do wait $p; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" obj/*.o
+echo "$HASH" > "$OUT.hash"
 echo "built $OUT"

@@ -379,6 +379,17 @@ int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int n
     return uvit_check_launch();
 }
 
+// A rank whose loss is not finite puts a NaN into its gradient arena BEFORE the all-reduce: the SUM carries it to every
+// rank, so all ranks see a non-finite gradient norm, skip AdamW / EMA (optim.hip) and stop together (the reference's
+// rank-local exit at engine_for_cyclical.py:166-168 would leave the peers blocked in the next collective).
+__global__ void poison_kernel(const float* __restrict__ loss, float* __restrict__ dst) {
+    if ((__float_as_uint(*loss) & 0x7F800000u) == 0x7F800000u) *dst = __int_as_float(0x7FC00000);
+}
+int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(poison_kernel, dim3(1), dim3(1), 0, s, loss, dst);
+    return uvit_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------
 // WassersteinLoss forward + backward (distloss.py:13-30, 73-79):
 //   pos_r = sum (sig(o)-sig(t))^2 + sum (sqrt(sig(co)) - sqrt(sig(ct)))^2 ; u = pos / max(pos)

@@ -17,6 +17,10 @@
 #define NREP 32
 #define RP(off) (e->grep + ((off) - e->lo.n_decay))   // replica 0 address of a no-decay gradient
 #define HIPCHECK(x) do { if ((x) != hipSuccess) return UVIT_ERR_LAUNCH; } while (0)
+// every GEMM launch of the engine carries the engine's own tuning (no process-wide launcher state)
+#define GEMM_NT(...) uvit_gemm_nt_launch(__VA_ARGS__, &e->tune)
+#define GEMM_TN(...) uvit_gemm_tn_launch(__VA_ARGS__, &e->tune)
+#define GEMM_TN_GROUP(...) uvit_gemm_tn_group_launch(__VA_ARGS__, &e->tune)
 
 // ------------------------------------------------------------------------------------------
 // layout
@@ -130,6 +134,7 @@ struct uvit_engine {
     Layout lo;
     int B, P, N, NP, C, Hd, H, Kpe, M, Mpad, BP, BPpad, chunk, nchunk;
     int S;                 // streams: 1 or 2
+    GemmTune tune;         // launch tuning of this engine's GEMMs (uvit_engine_set_tuning)
     int cur_B;             // batch of the last forward
     // workspace
     bf16* cols;
@@ -251,6 +256,10 @@ static void fill_dims(uvit_engine* e) {
 
 extern "C" void uvit_engine_destroy(uvit_engine* e);
 extern "C" int uvit_version(void) { return UVIT_VERSION; }
+#ifndef UVIT_SRC_HASH
+#define UVIT_SRC_HASH "unknown"
+#endif
+extern "C" const char* uvit_source_hash(void) { return UVIT_SRC_HASH; }
 
 extern "C" int uvit_layout_count(const uvit_config* cfg) {
     if (cfg_ok(cfg)) return UVIT_ERR_SHAPE;
@@ -346,11 +355,26 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     delete e;
 }
 
-extern "C" int uvit_set_gemm_variant(int v) { if (v != 0 && v != 1 && v != 3 && v != 5) return UVIT_ERR_ARG; uvit_gemm_set_variant(v); return UVIT_OK; }
+static int tune_from_abi(const uvit_tuning* t, GemmTune& g) {
+    if (!t) { g = GemmTune(); return UVIT_OK; }
+    if ((t->nt_variant != 0 && t->nt_variant != 1 && t->nt_variant != 3 && t->nt_variant != 5) ||
+        (t->tn_variant != 0 && t->tn_variant != 1 && t->tn_variant != 3) || t->tn_split_target < 0 || t->wgrad_group_chunks < 0)
+        return UVIT_ERR_ARG;
+    g.nt_variant = t->nt_variant; g.tn_variant = t->tn_variant;
+    g.tn_target = t->tn_split_target > 0 ? t->tn_split_target : 512; g.group_chunks = t->wgrad_group_chunks;
+    return UVIT_OK;
+}
 
-extern "C" int uvit_set_tn_variant(int v) { if (v != 0 && v != 1 && v != 3) return UVIT_ERR_ARG; uvit_gemm_set_tn_variant(v); return UVIT_OK; }
+extern "C" void uvit_tuning_default(uvit_tuning* out) {
+    if (!out) return;
+    const GemmTune d;
+    out->nt_variant = d.nt_variant; out->tn_variant = d.tn_variant; out->tn_split_target = d.tn_target; out->wgrad_group_chunks = d.group_chunks;
+}
 
-extern "C" int uvit_set_tn_split_target(int wgs) { uvit_gemm_set_tn_target(wgs); return UVIT_OK; }
+extern "C" int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t) {
+    if (!e) return UVIT_ERR_ARG;
+    return tune_from_abi(t, e->tune);
+}
 
 extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
     if (!e) return UVIT_ERR_ARG;
@@ -420,7 +444,7 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, Mall, C, e->cfg.ln_eps, s));
     for (int st = 0; st < S; ++st) {     // same qkv.weight for both streams (modeling_finetune_dist.py:121,127)
         GemmEpi q; q.out = a.qkv + st * Mp * 3 * C; q.bias = w.f + off_qb(o, st); q.bias2 = w.f + off_vb(o, st); q.ldo = 3 * C;
-        CHECK(uvit_gemm_nt_launch(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
+        CHECK(GEMM_NT(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
     }
     if (S == 1) {
         CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s));
@@ -431,19 +455,19 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     for (int st = 0; st < S; ++st) {
         GemmEpi p; p.out = x_mid + st * Mp * C; p.out2 = save ? a.projout + st * Mp * C : nullptr; p.bias = w.f + off_projb(o, st);
         p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
-        CHECK(uvit_gemm_nt_launch(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
+        CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
     }
     CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
     const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
     if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
-    CHECK(uvit_gemm_nt_launch(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
+    CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
     if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
     for (int st = 0; st < S; ++st) {
         GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
         f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
-        CHECK(uvit_gemm_nt_launch(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
+        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
     }
     return UVIT_OK;
 }
@@ -454,7 +478,7 @@ static int embed(uvit_engine* e, const Weights& w, const int64_t* mask, float* x
         float* x = x0 + (size_t)st * e->Mpad * e->C;
         GemmEpi pe; pe.out = x; pe.bias = w.f + (st ? e->lo.cpeb : e->lo.peb); pe.mask = mask;
         pe.mask_token = w.f + (st ? e->lo.cmask_tok : e->lo.mask_tok); pe.ldo = e->C; pe.patches = e->P;
-        CHECK(uvit_gemm_nt_launch(EPI_PATCH, e->cols, w.b + (st ? e->lo.cpew : e->lo.pew), Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
+        CHECK(GEMM_NT(EPI_PATCH, e->cols, w.b + (st ? e->lo.cpew : e->lo.pew), Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
         CHECK(uvit_set_cls_launch(x, w.f + (st ? e->lo.ccls : e->lo.cls), nullptr, Bc, e->N, e->C, s));
     }
     return UVIT_OK;
@@ -486,9 +510,10 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
         } else {
             float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
             CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s));
-            bool is_t = false;
-            for (int k = 0; k < hp_targets->n_target_layers; ++k) is_t |= hp_targets->target_layers[k] == l;
-            if (is_t) {
+            // `[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): a layer listed twice is summed twice and the
+            // mean divides by len(target_layers); the host has already mapped negative indices and refused out-of-range ones
+            for (int k = 0; k < hp_targets->n_target_layers; ++k) {
+                if (hp_targets->target_layers[k] != l) continue;
                 if (!hp_targets->target_layer_norm_last) return UVIT_ERR_ARG;
                 for (int st = 0; st < e->S; ++st)
                     CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
@@ -498,7 +523,7 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
         }
     }
     if (teacher && hp_targets) {
-        if (n_t == 0) return UVIT_ERR_ARG;
+        if (n_t != hp_targets->n_target_layers) return UVIT_ERR_ARG;     // an index outside [0, depth) reached the C ABI
         for (int st = 0; st < e->S; ++st)
             CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
     }
@@ -525,7 +550,7 @@ static int head_forward(uvit_engine* e, const Weights& w, int Bc, int st, bool a
                                  Bc * e->N, e->C, e->cfg.ln_eps, s));
         for (int b = 0; b < Bc; ++b) {
             GemmEpi h; h.out = out + (size_t)b * e->P * e->C; h.bias = w.f + lmb; h.ldo = e->C;
-            CHECK(uvit_gemm_nt_launch(EPI_F32, e->acts[0].ln1 + ((size_t)b * e->N + 1) * e->C, w.b + lmw, e->P, e->C, e->C,
+            CHECK(GEMM_NT(EPI_F32, e->acts[0].ln1 + ((size_t)b * e->N + 1) * e->C, w.b + lmw, e->P, e->C, e->C,
                                       e->C, e->C, &h, s));
         }
         return UVIT_OK;
@@ -533,7 +558,7 @@ static int head_forward(uvit_engine* e, const Weights& w, int Bc, int st, bool a
     CHECK(uvit_ln_fwd_gather_launch(x, e->rowidx, e->count, w.f + e->lo.normw, w.f + e->lo.normb, e->normed[st], e->meanF[st],
                                     e->rstdF[st], BP, e->C, e->cfg.ln_eps, s));
     GemmEpi h; h.out = out; h.bias = w.f + lmb; h.ldo = e->C;
-    CHECK(uvit_gemm_nt_launch(EPI_F32, e->normed[st], w.b + lmw, BP, e->C, e->C, e->C, e->C, &h, s));
+    CHECK(GEMM_NT(EPI_F32, e->normed[st], w.b + lmw, BP, e->C, e->C, e->C, e->C, &h, s));
     return UVIT_OK;
 }
 
@@ -609,9 +634,9 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     for (int st = 0; st < e->S; ++st) {
         const size_t lmw = st ? lo.clmw : lo.lmw, lmb = st ? lo.clmb : lo.lmb;
         CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, BP, RP(lmb), NREP, e->n_nd, s));
-        CHECK(uvit_gemm_tn_launch(e->dout[st], e->normed[st], e->BPpad, C, C, C, C, g + lmw, C, 1, s));
+        CHECK(GEMM_TN(e->dout[st], e->normed[st], e->BPpad, C, C, C, C, g + lmw, C, 1, s));
         GemmEpi d; d.out = e->dnormed[st]; d.ldo = C;
-        CHECK(uvit_gemm_nt_launch(EPI_BF16, e->dout[st], wt + lmw, BP, C, C, C, C, &d, s));
+        CHECK(GEMM_NT(EPI_BF16, e->dout[st], wt + lmw, BP, C, C, C, C, &d, s));
         // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
         CHECK(uvit_ln_bwd_scatter_launch(e->dnormed[st], e->X[e->cfg.depth] + (size_t)st * e->Mpad * C, e->rowidx, e->count,
                                          e->meanF[st], e->rstdF[st], e->buf.params + lo.normw, e->dXa + (size_t)st * e->Mpad * C,
@@ -664,7 +689,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         TnProb& qk = wg[nwg++]; qk.Y = dqkv; qk.X = a.ln1; qk.C = g + o.qkvw; qk.M = Mred; qk.Nn = 3 * C; qk.Kk = C; qk.ldy = 3 * C; qk.ldx = C; qk.ldc = C;
         if (S == 1) { qk.bias = RP(off_qb(o, 0)); qk.bias_end = C; qk.bias2 = RP(off_vb(o, 0)); qk.bias2_begin = 2 * C; }
     }
-    const bool grouped = uvit_gemm_tn_group_ok(wg, nwg);
+    const bool grouped = uvit_gemm_tn_group_ok(wg, nwg, &e->tune);
     // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
     // (the LayerScale backward of a branch rides in the LayerNorm backward that produces its input; in the two-stream
     //  model that kernel is launched once per stream, because drop-path scales and the proj bias differ per stream)
@@ -676,17 +701,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     e->ls_prefused = -1;
     if (!grouped) {
         CHECK(handoff(0));
-        CHECK(uvit_gemm_tn_launch(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+        CHECK(GEMM_TN(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
     }
     GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
-    CHECK(uvit_gemm_nt_launch(EPI_MULAUX, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));      // dH = (dY.W2) * gelu'(h)
+    CHECK(GEMM_NT(EPI_MULAUX, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));      // dH = (dY.W2) * gelu'(h)
     if (!grouped) {
         CHECK(handoff(1));
         CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));
-        CHECK(uvit_gemm_tn_launch(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
+        CHECK(GEMM_TN(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
     }
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
+    CHECK(GEMM_NT(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
     if (fuse_ls) {
         for (int st = 0; st < S; ++st) {
@@ -703,9 +728,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     if (!grouped) CHECK(handoff(2));
     for (int st = 0; st < S; ++st) {
-        if (!grouped) CHECK(uvit_gemm_tn_launch(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
+        if (!grouped) CHECK(GEMM_TN(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
         GemmEpi d3; d3.out = e->dAttn + st * Mp * C; d3.ldo = C;
-        CHECK(uvit_gemm_nt_launch(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), M, C, C, C, C, &d3, s));
+        CHECK(GEMM_NT(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), M, C, C, C, C, &d3, s));
     }
     const float* biasP = e->biasP_s;
     float* slabs = e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr;
@@ -724,11 +749,11 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
             CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
             CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));
         }
-    if (grouped) CHECK(uvit_gemm_tn_group_launch(wg, nwg, ws));
-    else CHECK(uvit_gemm_tn_launch(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
+    if (grouped) CHECK(GEMM_TN_GROUP(wg, nwg, ws));
+    else CHECK(GEMM_TN(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
-    CHECK(uvit_gemm_nt_launch(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
+    CHECK(GEMM_NT(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
     if (fuse_ls && l > 0) {
         // the MLP-branch LayerScale backward of layer l-1 writes dY1 of parity (l-1) & 1, last read by the wgrad of layer l+1
         if (e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
@@ -757,13 +782,14 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
         CHECK(uvit_token_bwd_launch(e->dXa + (size_t)st * e->Mpad * C, e->mask_copy, e->dpatch[st], g + (st ? lo.ccls : lo.cls),
                                     g + (st ? lo.cmask_tok : lo.mask_tok), e->B, e->P, C, s));
         CHECK(uvit_colsum_launch(e->dpatch[st], C, 0, C, BP, RP(st ? lo.cpeb : lo.peb), NREP, e->n_nd, s));
-        CHECK(uvit_gemm_tn_launch(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
+        CHECK(GEMM_TN(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
     }
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed
     // fold the replicated column-sum accumulators into the no-decay gradients
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
+    CHECK(uvit_poison_if_nonfinite_launch(e->loss, g + lo.n_decay, s));     // non-finite loss -> every rank's norm is NaN
     return UVIT_OK;
 }
 
@@ -783,9 +809,9 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
     const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
     CHECK(uvit_adamw_launch(e->buf.params, e->buf.grads, e->buf.adam_m, e->buf.adam_v, e->buf.params_bf16, lo.n_live, lo.n_decay,
                             hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
-                            e->gnorm, s));
+                            e->gnorm, s, e->loss));
     CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
-    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_live, hp->ema_decay, s));
+    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_live, hp->ema_decay, s, e->loss, e->sumsq));
     return UVIT_OK;
 }
 
@@ -809,16 +835,27 @@ extern "C" int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_str
 // operator-level C ABI (thin wrappers over the internal launchers)
 // ------------------------------------------------------------------------------------------
 #define S(x) ((hipStream_t)(x))
-extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
-                               const uvit_gemm_epilogue* ep, uvit_stream st) {
+extern "C" int uvit_op_gemm_nt_tuned(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                                     const uvit_gemm_epilogue* ep, const uvit_tuning* tune, int* tail_rows, uvit_stream st) {
     if (!A || !W || !ep || !ep->out) return UVIT_ERR_ARG;
+    GemmTune tu;
+    const int trc = tune_from_abi(tune, tu);
+    if (trc) return trc;
     GemmEpi g; g.out = ep->out; g.out2 = ep->out2; g.bias = ep->bias; g.bias2 = ep->bias2; g.gamma = ep->gamma;
     g.resid = ep->resid; g.rowscale = ep->rowscale; g.aux = ep->aux; g.mask = ep->mask; g.mask_token = ep->mask_token;
     g.ldo = ep->ldo; g.tokens = ep->tokens > 0 ? ep->tokens : 1; g.patches = ep->patches > 0 ? ep->patches : 1;
-    return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st));
+    g.row0 = ep->row0;
+    return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st), &tu, tail_rows);
 }
-extern "C" int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, uvit_stream st) {
+extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                               const uvit_gemm_epilogue* ep, uvit_stream st) {
+    return uvit_op_gemm_nt_tuned(mode, A, W, M, N, K, lda, ldw, ep, nullptr, nullptr, st);
+}
+extern "C" int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, const uvit_tuning* tune, uvit_stream st) {
     if (!problems || count < 1 || count > UVIT_TN_GROUP_MAX) return UVIT_ERR_ARG;
+    GemmTune tu;
+    const int trc = tune_from_abi(tune, tu);
+    if (trc) return trc;
     TnProb pr[UVIT_TN_GROUP_MAX];
     for (int i = 0; i < count; ++i) {
         const uvit_wgrad_problem& q = problems[i];
@@ -827,15 +864,17 @@ extern "C" int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count
         pr[i].bias_end = q.bias_end; pr[i].bias2_begin = q.bias2_begin;
         pr[i].M = q.M; pr[i].Nn = q.N; pr[i].Kk = q.K; pr[i].ldy = q.ldy; pr[i].ldx = q.ldx; pr[i].ldc = q.ldc;
     }
-    return uvit_gemm_tn_group_launch(pr, count, S(st));
+    return uvit_gemm_tn_group_launch(pr, count, S(st), &tu);
 }
 
-extern "C" int uvit_set_wgrad_group_chunks(int chunks) { if (chunks < 0) return UVIT_ERR_ARG; uvit_gemm_set_tn_group_chunks(chunks); return UVIT_OK; }
-
-extern "C" int uvit_op_gemm_tn(const void* Y, const void* X, int M, int N, int K, int ldy, int ldx, float* C, int ldc, uvit_stream st) {
+extern "C" int uvit_op_gemm_tn(const void* Y, const void* X, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
+                               const uvit_tuning* tune, uvit_stream st) {
     if (!Y || !X || !C) return UVIT_ERR_ARG;
+    GemmTune tu;
+    const int trc = tune_from_abi(tune, tu);
+    if (trc) return trc;
     if (hipMemsetAsync(C, 0, (size_t)N * ldc * sizeof(float), S(st)) != hipSuccess) return UVIT_ERR_LAUNCH;
-    return uvit_gemm_tn_launch(Y, X, M, N, K, ldy, ldx, C, ldc, 1, S(st));
+    return uvit_gemm_tn_launch(Y, X, M, N, K, ldy, ldx, C, ldc, 1, S(st), &tu);
 }
 extern "C" int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
                                 float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
@@ -885,6 +924,11 @@ extern "C" int uvit_op_adamw(float* p, const float* g, float* m, float* v, void*
 extern "C" int uvit_op_smooth_l1(const float* out, const float* target, const int32_t* count, float beta, int l2, float ls,
                                  float* loss, void* dout, int Mmax, int C, uvit_stream st) {
     return uvit_smooth_l1_launch(out, target, count, beta, l2, ls, loss, dout, Mmax, C, S(st));
+}
+extern "C" int uvit_op_wasserstein_loss(const float* om, const float* oc, const float* tm, const float* tc, const int32_t* count, float lam,
+                                        float ls, float* scratch, float* loss, void* dm, void* dc, int Mmax, int C, uvit_stream st) {
+    if (!om || !oc || !tm || !tc || !count || !scratch || !loss || !dm || !dc || Mmax < 1 || C < 1) return UVIT_ERR_ARG;
+    return uvit_wasserstein_loss_launch(om, oc, tm, tc, count, lam, ls, scratch, loss, dm, dc, Mmax, C, S(st));
 }
 extern "C" int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
                                     int C, float eps, uvit_stream st) {

@@ -11,6 +11,8 @@
 // The MFMA is issued "swapped" (weight rows as the A operand) so that each lane ends up with 4
 // consecutive output columns of one output row -> 8/16-byte vector epilogue loads and stores.
 // Epilogues fuse bias, GELU, LayerScale*DropPath*residual, GELU', mask-token blend.
+#include <mutex>
+
 #include "common.h"
 #include "uvit_internal.h"
 
@@ -932,21 +934,15 @@ void gemm_tn256_group_kernel(const TnGroup G) {
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-static bool g_attr_done = false;
-static int g_variant = 3;
-static int g_tn_variant = 3;      // 0: 128x128, 1: 256x256 staggered, 3: auto
-void uvit_gemm_set_tn_variant(int v) { g_tn_variant = (v == 0 || v == 1) ? v : 3; }
-static int g_tn_group_chunks = 0;  // 0: chosen by the cost model below
-void uvit_gemm_set_tn_group_chunks(int n) { g_tn_group_chunks = n > 0 ? n : 0; }
+// Tuning knobs travel with the caller (engine object / operator call): no mutable process-wide launcher state.
+// The only process-wide data are write-once caches of device facts (CU count, LDS opt-in), set under std::call_once.
+static std::once_flag g_init_flag;
 static int g_num_cu = 256;
-static int g_tn_target = 512;     // MI355X sweep (tools/bench_gemm.py): 512 beats 256..1536 on all four wgrad shapes
-void uvit_gemm_set_tn_target(int wgs) { g_tn_target = wgs > 0 ? wgs : 512; }
-void uvit_gemm_set_variant(int v) { g_variant = (v == 0 || v == 1 || v == 5) ? v : 3; }
+static const GemmTune g_default_tune;
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
-static void gemm_init_once() {
-    if (g_attr_done) return;
+static void gemm_init_impl() {
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
@@ -961,11 +957,14 @@ static void gemm_init_once() {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         g_num_cu = prop.multiProcessorCount;
-    g_attr_done = true;
 }
+static void gemm_init_once() { std::call_once(g_init_flag, gemm_init_impl); }
 
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
-                        const GemmEpi* epi, hipStream_t s) {
+                        const GemmEpi* epi, hipStream_t s, const GemmTune* tune, int* tail_rows_out) {
+    const GemmTune& tu = tune ? *tune : g_default_tune;
+    const int nt_variant = tu.nt_variant;
+    if (tail_rows_out) *tail_rows_out = 0;
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N % 8) || (lda % 8) || (ldw % 8) || (epi->ldo % 4))
         return UVIT_ERR_SHAPE;
     gemm_init_once();
@@ -979,7 +978,7 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     // instead of 297 = 1.16 rounds of 256-row tiles).
     const bool shape_ok = (N % 256) == 0 && M >= 1024 && K >= 128 && (K % 64) == 0 &&
                           (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;     // 32-bit operand offsets
-    int variant = shape_ok ? g_variant : 0;
+    int variant = shape_ok ? nt_variant : 0;
     int mt = 4;
     if (variant == 5) { variant = 1; mt = 5; }
     else if (variant == 3) {
@@ -992,7 +991,7 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     // 256-row tiles that overflow whole rounds of the CUs by only a few tiles would run a nearly empty last round: the
     // overflowing row tiles go to the 128x128 kernel instead (second launch below)
     int m_tail = 0;
-    if (variant == 1 && mt == 4 && g_variant == 3 && mode != EPI_PATCH) {
+    if (variant == 1 && mt == 4 && nt_variant == 3 && mode != EPI_PATCH) {
         const int tiles_n = N / T_BN, tiles = ((M + T_BM - 1) / T_BM) * tiles_n;
         const int rounds = tiles / g_num_cu, over = tiles - rounds * g_num_cu;
         if (rounds >= 1 && over > 0 && over * 4 <= g_num_cu) {
@@ -1032,20 +1031,22 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
         if (t.resid) t.resid = t.resid + r0 * t.ldo;
         if (t.aux) t.aux = (const void*)((const bf16*)t.aux + r0 * t.ldo);
         t.row0 = epi->row0 + (int)r0;
-        const int saved = g_variant;
-        g_variant = 0;
-        rc = uvit_gemm_nt_launch(mode, a + r0 * lda, W, m_tail, N, K, lda, ldw, &t, s);
-        g_variant = saved;
+        GemmTune generic;                                  // the tail always runs on the 128x128 kernel
+        generic.nt_variant = 0;
+        rc = uvit_gemm_nt_launch(mode, a + r0 * lda, W, m_tail, N, K, lda, ldw, &t, s, &generic, nullptr);
+        if (tail_rows_out) *tail_rows_out = m_tail;
     }
     return rc;
 }
 
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
-                        int ldc, int allow_split, hipStream_t s) {
+                        int ldc, int allow_split, hipStream_t s, const GemmTune* tune) {
+    const GemmTune& tu = tune ? *tune : g_default_tune;
+    const int tn_variant = tu.tn_variant, tn_target = tu.tn_target > 0 ? tu.tn_target : 512;
     if (M <= 0 || (M % BK) || (Nn % 8) || (Kk % 8) || (ldy % 8) || (ldx % 8) || (ldc % 4)) return UVIT_ERR_SHAPE;
     gemm_init_once();
     const int nm = M / BK;
-    if (g_tn_variant == 1 && (Nn % T_BM) == 0 && (Kk % T_BN) == 0 && nm >= 8) {
+    if (tn_variant == 1 && (Nn % T_BM) == 0 && (Kk % T_BN) == 0 && nm >= 8) {
         // 256x256 tiles, one workgroup per CU: split the token reduction until ~256 workgroups exist
         const int tiles256 = (Nn / T_BM) * (Kk / T_BN);
         int split = allow_split ? (256 + tiles256 / 2) / tiles256 : 1;
@@ -1061,7 +1062,7 @@ int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int
     // split the token reduction until ~1024 workgroups are in flight (2 resident per CU x 256 CUs, two rounds)
     int split = 1;
     if (allow_split) {
-        split = g_tn_target / tiles;
+        split = tn_target / tiles;
         if (split > nm / 8) split = nm / 8;
         if (split < 1) split = 1;
     }
@@ -1075,8 +1076,8 @@ int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int
 // Grouped wgrad: every problem needs Nn, Kk multiples of 256 (bias segments too) and a token count that is a
 // multiple of 64.  Returns UVIT_ERR_SHAPE without launching when the group does not qualify (callers fall back to
 // per-problem launches).
-bool uvit_gemm_tn_group_ok(const TnProb* probs, int n) {
-    if (n < 1 || n > UVIT_TN_GROUP_MAX || g_tn_variant == 0) return false;
+bool uvit_gemm_tn_group_ok(const TnProb* probs, int n, const GemmTune* tune) {
+    if (n < 1 || n > UVIT_TN_GROUP_MAX || (tune ? tune : &g_default_tune)->tn_variant == 0) return false;
     for (int i = 0; i < n; ++i) {
         const TnProb& q = probs[i];
         if (q.M <= 0 || (q.M % BK) || q.M / BK < 8 || (q.Nn % T_BM) || (q.Kk % T_BN) || (q.ldy % 8) || (q.ldx % 8) || (q.ldc % 4)) return false;
@@ -1085,8 +1086,9 @@ bool uvit_gemm_tn_group_ok(const TnProb* probs, int n) {
     return true;
 }
 
-int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s) {
-    if (!uvit_gemm_tn_group_ok(probs, n)) return UVIT_ERR_SHAPE;
+int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const GemmTune* tune) {
+    if (!uvit_gemm_tn_group_ok(probs, n, tune)) return UVIT_ERR_SHAPE;
+    const int group_chunks = (tune ? tune : &g_default_tune)->group_chunks;
     gemm_init_once();
     TnGroup G;
     G.nprob = n;
@@ -1119,7 +1121,7 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s) {
         const double cost = (double)((items + g_num_cu - 1) / g_num_cu) * L + atomic_bytes / 2.6e6 + 6.0;
         if (cost < best_cost) { best_cost = cost; best_sp = sp; }
     }
-    if (g_tn_group_chunks > 0) best_sp = g_tn_group_chunks < (nm_max / 4 > 1 ? nm_max / 4 : 1) ? g_tn_group_chunks : (nm_max / 4 > 1 ? nm_max / 4 : 1);
+    if (group_chunks > 0) best_sp = group_chunks < (nm_max / 4 > 1 ? nm_max / 4 : 1) ? group_chunks : (nm_max / 4 > 1 ? nm_max / 4 : 1);
     int items; const int L = plan(best_sp, items);
     G.max_chunks = 0;
     for (int i = 0; i < n; ++i) {

@@ -7,8 +7,18 @@
 #include "common.h"
 #include "uvit_internal.h"
 
+// A step whose loss or gradient norm is not finite must leave the weights as they were: the reference stops BEFORE
+// backward / optimizer.step / EMA (engine_for_cyclical.py:166-168).  Both kernels test the device-side values, so the
+// decision needs no host round trip and is identical on every rank (the norm is taken after the all-reduce).
+__device__ __forceinline__ bool not_finite(float x) { return (__float_as_uint(x) & 0x7F800000u) == 0x7F800000u; }
+__device__ __forceinline__ bool step_poisoned(const float* loss, const double* sumsq) {
+    return (loss && not_finite(*loss)) || (sumsq && not_finite((float)*sumsq));
+}
+
 __global__ __launch_bounds__(256)
-void ema_kernel(float* __restrict__ e, const float* __restrict__ p, bf16* __restrict__ eb, size_t n4, float d) {
+void ema_kernel(float* __restrict__ e, const float* __restrict__ p, bf16* __restrict__ eb, size_t n4, float d,
+                const float* __restrict__ guard_loss, const double* __restrict__ guard_sumsq) {
+    if (step_poisoned(guard_loss, guard_sumsq)) return;
     const float om = 1.0f - d;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 a = ((const float4*)e)[i];
@@ -42,13 +52,14 @@ __global__ __launch_bounds__(256)
 void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                   bf16* __restrict__ pb, size_t n4, size_t n4_decay, float lr, float wd, float b1, float b2, float eps,
                   float bc1, float bc2_sqrt, const double* __restrict__ sumsq, float max_norm, float grad_scale,
-                  float* __restrict__ gnorm_out) {
+                  float* __restrict__ gnorm_out, const float* __restrict__ guard_loss) {
     float coef = grad_scale;
     if (sumsq) {
         const float norm = (float)sqrt(*sumsq) * grad_scale;
         if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = norm;
         if (max_norm > 0.f) coef *= fminf(max_norm / (norm + 1e-6f), 1.0f);
     }
+    if (step_poisoned(guard_loss, sumsq)) return;
     const float step_size = lr / bc1;
     const float decay = 1.0f - lr * wd;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -84,9 +95,10 @@ static inline int stream_grid(size_t n4) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s) {
+int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s, const float* guard_loss,
+                    const double* guard_sumsq) {
     if (n % 4) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(ema_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, ema, p, (bf16*)ema_bf16, n / 4, decay);
+    hipLaunchKernelGGL(ema_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, ema, p, (bf16*)ema_bf16, n / 4, decay, guard_loss, guard_sumsq);
     return uvit_check_launch();
 }
 int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s) {
@@ -96,12 +108,12 @@ int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s) {
 }
 int uvit_adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, size_t n_decay, float lr,
                       float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
-                      float grad_scale, float* gnorm_out, hipStream_t s) {
+                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss) {
     if (n % 4 || n_decay % 4 || step < 1) return UVIT_ERR_SHAPE;
     const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n / 4, n_decay / 4,
-                       lr, wd, b1, b2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale, gnorm_out);
+                       lr, wd, b1, b2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale, gnorm_out, guard_loss);
     return uvit_check_launch();
 }
 int uvit_cast_bf16_launch(const float* src, void* dst, size_t n, hipStream_t s) {

@@ -25,14 +25,20 @@ struct GemmEpi {
 };
 
 // gemm.hip
+// Launch tuning (mirrors uvit_tuning in include/uvit.h).  Passed by the caller on every launch: the launchers keep no
+// mutable process-wide state, so host threads launching on different streams do not interact.
+struct GemmTune {
+    int nt_variant = 3;      // 0: 128x128, 1: 256x256 staggered (1 WG/CU), 5: 320x256, 3: auto by shape
+    int tn_variant = 3;      // 0: 128x128 kernel, 1: 256x256 staggered kernel, 3: auto
+    int tn_target = 512;     // workgroups the wgrad split-K aims for (MI355X sweep: 512 beats 256..1536 on all four wgrad shapes)
+    int group_chunks = 0;    // grouped wgrad: 0 = cost model, > 0 = forced token-chunk count
+};
+// tune == nullptr: defaults.  tail_rows_out (nullable) receives the rows that went to the row-split tail launch.
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
-                        const GemmEpi* epi, hipStream_t s);
-void uvit_gemm_set_variant(int v);   // 0: 128x128, 1: 256x256 staggered (1 WG/CU), 3: auto by shape
-void uvit_gemm_set_tn_variant(int v);    // 0: 128x128 kernel, 1: 256x256 staggered kernel, 3: auto
-void uvit_gemm_set_tn_target(int wgs);   // workgroups the wgrad split-K aims for
+                        const GemmEpi* epi, hipStream_t s, const GemmTune* tune = nullptr, int* tail_rows_out = nullptr);
 // allow_split: partial sums are combined with fp32 atomics -> C must be zero (or hold a value to add to)
 int uvit_gemm_tn_launch(const void* Y, const void* X, int M, int Nn, int Kk, int ldy, int ldx, float* C,
-                        int ldc, int allow_split, hipStream_t s);
+                        int ldc, int allow_split, hipStream_t s, const GemmTune* tune = nullptr);
 
 // grouped wgrad (all Linear weight gradients of one layer in one launch, bias column sums fused)
 #define UVIT_TN_GROUP_MAX 6
@@ -48,9 +54,8 @@ struct TnProb {
     int nm = 0, tiles_n = 0, tiles_k = 0, chunk_steps = 0, chunks = 0;
 };
 struct TnGroup { TnProb p[UVIT_TN_GROUP_MAX]; int nprob = 0; int max_chunks = 0; };
-bool uvit_gemm_tn_group_ok(const TnProb* probs, int n);
-int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s);
-void uvit_gemm_set_tn_group_chunks(int n);   // 0: cost model; > 0: forced token-chunk count
+bool uvit_gemm_tn_group_ok(const TnProb* probs, int n, const GemmTune* tune = nullptr);
+int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const GemmTune* tune = nullptr);
 
 // attention.hip
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
@@ -108,16 +113,19 @@ int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf1
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
 int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step,
                          hipStream_t s);
+int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, hipStream_t s);
 int uvit_wasserstein_loss_launch(const float* out_m, const float* out_c, const float* tgt_m, const float* tgt_c, const int* count,
                                  float lam, float loss_scale, float* scratch, float* loss, void* dout_m_bf16, void* dout_c_bf16,
                                  int Mmax, int C, hipStream_t s);
 
 // optim.hip
-int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s);
+// guard_loss / guard_sumsq (nullable, device): the update is skipped when either holds a non-finite value
+int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float decay, hipStream_t s, const float* guard_loss = nullptr,
+                    const double* guard_sumsq = nullptr);
 int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s);
 int uvit_adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, size_t n_decay, float lr,
                       float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
-                      float grad_scale, float* gnorm_out, hipStream_t s);
+                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss = nullptr);
 int uvit_cast_bf16_launch(const float* src, void* dst_bf16, size_t n, hipStream_t s);
 
 struct TransposeDesc { const void* src; void* dst; int rows; int cols; int tile0; int pad; };

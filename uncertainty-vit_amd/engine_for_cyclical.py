@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import utils
-from .native import StepParams, check, cur_stream, lib, ptr
+from .native import MAX_DEPTH, StepParams, check, cur_stream, lib, ptr
 
 
 def _unwrap(model):
@@ -28,8 +28,12 @@ class GradReducer:
     """Bucketed all-reduce(SUM) of the flat gradient arena, launched as soon as a block's
     gradients are final (the reference gets this from DDP hooks, run_cyclical.py:515-519)."""
 
-    def __init__(self, model, enabled):
+    def __init__(self, model, enabled, comm_dtype=torch.float32):
+        """comm_dtype=torch.bfloat16: each bucket is rounded to bf16 for the wire (164.5 MB instead of 329 MB per step
+        for ViT-B), summed by RCCL in bf16 and widened back into the fp32 gradient arena; the clip norm, AdamW
+        and its moments stay fp32.  Default fp32 = DDP's arithmetic (run_cyclical.py:515-519)."""
         self.enabled = enabled and utils.get_world_size() > 1
+        self.comm_dtype = comm_dtype
         if not self.enabled:
             return
         self.world = utils.get_world_size()
@@ -60,15 +64,28 @@ class GradReducer:
             if layer is not None:      # the block's wgrads run on the engine's second stream
                 check(lib().uvit_step_wait_layer_grads(engine.h, layer, C.c_void_p(self.comm.cuda_stream)), "wait_layer_grads")
             with torch.cuda.stream(self.comm):
-                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                self._all_reduce(view)
         else:
-            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self._all_reduce(view)
+
+    def _all_reduce(self, view):
+        if self.comm_dtype == torch.float32:
+            self.pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True), None, None))
+        else:
+            wire = view.to(self.comm_dtype)
+            self.pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True), wire, view))
 
     def finish(self):
         if not self.enabled:
             return
-        for w in self.pending:
+        for w, wire, view in self.pending:
             w.wait()
+            if wire is not None:
+                if self.on_gpu:
+                    with torch.cuda.stream(self.comm):
+                        view.copy_(wire)
+                else:
+                    view.copy_(wire)
         self.pending = []
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.comm)
@@ -136,10 +153,20 @@ def native_step(engine, reducer, samples, mask, hp):
 
 
 def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
-                     post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5):
+                     post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5,
+                     depth=None):
     hp = StepParams()
+    if len(target_layers) > MAX_DEPTH:
+        raise ValueError(f"at most {MAX_DEPTH} target layers")
     for i, t in enumerate(target_layers):
-        hp.target_layers[i] = int(t)
+        # `[targets[i] for i in target_layers]` (engine_for_cyclical.py:92) is Python list indexing: negative indices count
+        # from the last block, anything outside [-depth, depth) raises IndexError, a repeated index is averaged twice
+        t = int(t)
+        if depth is not None:
+            if not -depth <= t < depth:
+                raise IndexError("list index out of range")
+            t = t % depth
+        hp.target_layers[i] = t
     hp.n_target_layers = len(target_layers)
     hp.target_layer_norm_last = int(bool(target_layer_norm_last))
     hp.post_target_layer_norm = int(bool(post_target_layer_norm))
@@ -221,14 +248,19 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
         if not do_ema:
             cur_decay = 0
         hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
-                              post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining)
+                              post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining,
+                              depth=net.depth)
         native_step(engine, reducer, samples, mask, hp)
         optimizer.step_count += 1
 
         # one host sync per step, as the reference (loss.item() + torch.cuda.synchronize())
         check(lib().uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "read_stats")
         loss_value, grad_norm = float(stats[0]), float(stats[1])
-        if not math.isfinite(loss_value):
+        if not (math.isfinite(loss_value) and math.isfinite(grad_norm)):
+            # The reference stops before backward / optimizer.step / EMA (engine_for_cyclical.py:166-168); here the step was
+            # already enqueued, so AdamW and EMA test the device-side loss and (all-reduced) gradient norm themselves and
+            # leave the weights untouched.  The all-reduced norm is NaN on EVERY rank when any rank's loss was, so all ranks
+            # take this exit together instead of one leaving its peers blocked in the next collective.
             print("Loss is {}, stopping training".format(loss_value), force=True) if world > 1 else \
                 print("Loss is {}, stopping training".format(loss_value))
             sys.exit(1)

@@ -62,13 +62,29 @@ class WgradProblem(C.Structure):
 
 class GemmEpilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("out", "out2", "bias", "bias2", "gamma", "resid", "rowscale", "aux", "mask",
-                                           "mask_token")] + [("ldo", C.c_int32), ("tokens", C.c_int32), ("patches", C.c_int32)]
+                                           "mask_token")] + [("ldo", C.c_int32), ("tokens", C.c_int32), ("patches", C.c_int32),
+                                                             ("row0", C.c_int32)]
+
+
+class Tuning(C.Structure):
+    """uvit_tuning (include/uvit.h): launch tuning passed per call / held by the engine."""
+    _fields_ = [("nt_variant", C.c_int32), ("tn_variant", C.c_int32), ("tn_split_target", C.c_int32),
+                ("wgrad_group_chunks", C.c_int32)]
+
+    @classmethod
+    def default(cls, **over):
+        t = cls()
+        lib().uvit_tuning_default(C.byref(t))
+        for k, v in over.items():
+            setattr(t, k, v)
+        return t
 
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 # prototypes of every symbol include/uvit.h declares (argtypes matter: int64 / float arguments)
 _PROTOTYPES = {
     "uvit_version": (_i, []),
+    "uvit_source_hash": (C.c_char_p, []),
     "uvit_layout_count": (_i, [_vp]),
     "uvit_layout_get": (_i, [_vp, _i, _vp]),
     "uvit_arena_numel": (_i64, [_vp, _vp]),
@@ -86,16 +102,16 @@ _PROTOTYPES = {
     "uvit_step_update": (_i, [_vp, _vp, _vp]),
     "uvit_train_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_engine_read_stats": (_i, [_vp, _vp, _vp]),
-    "uvit_set_gemm_variant": (_i, [_i]),
-    "uvit_set_tn_variant": (_i, [_i]),
-    "uvit_set_wgrad_group_chunks": (_i, [_i]),
-    "uvit_op_wgrad_group": (_i, [_vp, _i, _vp]),
-    "uvit_set_tn_split_target": (_i, [_i]),
+    "uvit_tuning_default": (None, [_vp]),
+    "uvit_engine_set_tuning": (_i, [_vp, _vp]),
+    "uvit_op_wgrad_group": (_i, [_vp, _i, _vp, _vp]),
     "uvit_engine_set_streams": (_i, [_vp, _i]),
     "uvit_engine_profile": (_i, [_vp, _i, _i]),
     "uvit_engine_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "uvit_op_gemm_nt": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "uvit_op_gemm_tn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "uvit_op_gemm_nt_tuned": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "uvit_op_gemm_tn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "uvit_op_wasserstein_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "uvit_op_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_attn2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
@@ -120,14 +136,29 @@ SYMBOLS = list(_PROTOTYPES)
 _lib = None
 
 
+def source_hash():
+    """Fingerprint of csrc/{*.hip,*.h} + include/uvit.h as csrc/build.sh computes it."""
+    import hashlib
+    src = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for f in sorted(n for n in os.listdir(src) if n.endswith((".hip", ".h"))):
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(_HERE, "..", "include", "uvit.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile csrc/*.hip for gfx950 into libuvit.so (hipcc cross-compiles without a GPU)."""
     if os.path.exists(LIB_PATH) and not force:
-        src = os.path.join(_HERE, "csrc")
-        newest = max(os.path.getmtime(os.path.join(src, f)) for f in os.listdir(src) if f.endswith((".hip", ".h")))
-        newest = max(newest, os.path.getmtime(os.path.join(_HERE, "..", "include", "uvit.h")))
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+        # build.sh leaves the fingerprint beside the library (dlopen-ing the old file here would pin it in this process)
+        try:
+            with open(LIB_PATH + ".hash") as fh:
+                if fh.read().strip() == source_hash():
+                    return LIB_PATH
+        except OSError:
+            pass
     subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh"), LIB_PATH], check=True)
     return LIB_PATH
 
@@ -146,6 +177,11 @@ def lib():
         f.restype, f.argtypes = res, args
     if L.uvit_version() != 100:
         raise UvitError("libuvit version mismatch")
+    built, want = L.uvit_source_hash().decode(), source_hash()
+    if built != want:
+        # never auto-build here: lib() runs inside profiled / multi-rank processes
+        raise UvitError(f"{LIB_PATH} is stale: built from sources {built}, on disk {want}. "
+                        "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
     _lib = L
     return L
 
