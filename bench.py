@@ -87,6 +87,43 @@ def cpu_baseline(sample_bs=4, steps=3):
             "reference_engine_build_container": REFERENCE_ENGINE_BUILD_CONTAINER}
 
 
+def input_staging_rates(a, L, feed, step, fence, dev, x, mask, steps=8):
+    """SURVEY 8f-1, measured beside (never instead of) `value`: the same step fed (a) from pinned host memory through the
+    double-buffered prefetcher of engine_for_cyclical.DevicePrefetcher -- batch i+1 crosses PCIe on a side stream while step i
+    computes -- and (b) by the on-device batch synthesis kernels (uvit_op_synth_batch), a fresh batch every step."""
+    from uncertainty_vit_amd.engine_for_cyclical import DevicePrefetcher
+    from uncertainty_vit_amd.native import check
+    out = {}
+    host = [((x.cpu().pin_memory(), mask.cpu().pin_memory()), 0), ((x.flip(0).cpu().pin_memory(), mask.flip(0).cpu().pin_memory()), 0)]
+    batches = [host[i % 2] for i in range(steps + 2)]
+    i0 = 10_000
+    fence()
+    t0 = None
+    for i, ((xs, ms), _) in enumerate(DevicePrefetcher(batches, dev)):
+        if i == 2:
+            fence(); t0 = time.perf_counter()
+        feed["x"], feed["mask"] = xs, ms.reshape(a.batch, -1).contiguous()
+        step(i0 + i)
+    fence()
+    dt = time.perf_counter() - t0
+    out["value_with_h2d"] = round(a.batch * steps / dt, 2)
+    out["h2d"] = f"{steps} steps fed from pinned host memory, H2D of batch i+1 ({x.numel() * 4 / 1e6:.0f} MB) on a side stream beside step i"
+    xs, ms = torch.empty_like(x), torch.empty_like(mask)
+    feed["x"], feed["mask"] = xs, ms
+    n_mask = int(mask[0].sum().item())
+    fence(); t0 = time.perf_counter()
+    for i in range(steps):
+        check(L.uvit_op_synth_batch(C.c_void_p(xs.data_ptr()), C.c_void_p(ms.data_ptr()), a.batch, 3, x.shape[-1], ms.shape[1], n_mask,
+                                    4321, i, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "synth_batch")
+        step(i0 + 100 + i)
+    fence()
+    dt = time.perf_counter() - t0
+    out["value_with_device_synth"] = round(a.batch * steps / dt, 2)
+    out["device_synth"] = f"{steps} steps, a fresh N(0,1) batch + exactly-{n_mask}-ones masks generated on the GPU inside every step"
+    feed["x"], feed["mask"] = x, mask
+    return out
+
+
 def self_launch(a):
     """--gpus N > 1 without a launcher: start N ranks (one process per GPU) before any GPU call and mirror their exit code."""
     import socket
@@ -116,6 +153,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE config: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-input-staging", action="store_true", help="skip the two extra short regions that time H2D-fed and device-synthesised batches")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce buckets (bf16 halves the xGMI bytes; AdamW accumulates in fp32 either way)")
@@ -175,12 +213,14 @@ def main():
         check(L.uvit_engine_set_tuning(engine.h, C.byref(tu)), "set_tuning")
     seed = 1000 + rank             # run_cyclical.py:315 seeds with seed + rank: every rank draws its own dropout / drop-path masks
 
+    feed = {"x": x, "mask": mask}      # what a step consumes (swapped by the input-staging regions below)
+
     def step(i):
         depth = model.depth
         hp = make_step_params(list(range(depth // 2, depth)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, seed, i,
                               lambda_pretraining=1e-5, depth=depth)
         hp.lr = 2e-5       # warm-up-sized lr: random-init weights and fixed synthetic data, 2e-3 is the post-warm-up peak
-        native_step(engine, reducer, x, mask, hp)
+        native_step(engine, reducer, feed["x"], feed["mask"], hp)
         opt.step_count += 1
 
     def fence():
@@ -220,6 +260,9 @@ def main():
         check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
     stats = torch.zeros(2).pin_memory()
     check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
+    staging = None
+    if world == 1 and not a.no_input_staging:
+        staging = input_staging_rates(a, L, feed, step, fence, dev, x, mask)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,6 +297,7 @@ def main():
                              "frac": round(flops / (alone_ms * 1e-3) / PEAK_BF16, 4),
                              "measured": "3 single-stream steps right after the timed region (kernel alone on the GPU)"}},
             "rccl_ranks": world,
+            "input_staging": staging,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

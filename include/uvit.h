@@ -84,6 +84,13 @@ typedef struct uvit_step_params {
     uint32_t it;                      /* global iteration, decorrelates masks between steps */
     int32_t train_dropout;            /* 1: apply attn_drop_rate and drop_path_rate in the student */
     float lambda_pretraining;         /* WassersteinLoss weight (two-stream model only; --lambda_pretraining) */
+    /* Device-resident schedules (utils.py:408-459 tables + the EMA decay anneal / tri-phase cut-off of
+     * engine_for_cyclical.py:55-56,182-185): sched_dev = float[3][sched_len] = {lr, weight_decay, ema_decay} per iteration,
+     * ema_decay < 0 meaning "skip EMA".  When non-NULL the optimizer kernels read entry `sched_index` on the device and the
+     * scalar fields lr / weight_decay / ema_decay / do_ema above are ignored: the step's launch arguments then do not
+     * depend on the iteration (a captured step can be replayed). */
+    const float* sched_dev;
+    int32_t sched_len, sched_index;
 } uvit_step_params;
 
 int uvit_version(void);
@@ -141,7 +148,8 @@ int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, co
 /* Launch tuning.  It is an ARGUMENT (engine member / operator-call parameter), never process-wide state, so host
  * threads that launch on different streams cannot disturb one another.
  *   nt_variant: NT GEMM kernel for large shapes: 3 = auto by shape (default), 1 = 256x256 tile with staggered wave
- *               groups (one workgroup per CU), 5 = the same kernel with 320x256 tiles, 0 = 128x128 generic kernel;
+ *               groups (one workgroup per CU), 5 = the same kernel with 320x256 tiles, 0 = 128x128 generic kernel,
+ *               6 / 7 = ring kernel (two workgroups per CU, 3-deep 32-k ring) with 128- / 160-row tiles;
  *   tn_variant: wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128;
  *   tn_split_target: workgroups the wgrad token split aims for (default 512);
  *   wgrad_group_chunks: token chunks per output tile of uvit_op_wgrad_group (0 = cost model, default). */
@@ -158,6 +166,11 @@ int uvit_engine_set_streams(uvit_engine* e, int dual);
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */
 int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
 int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
+/* enqueues the copy of {loss, grad_norm} of the last step into (pinned) host memory behind the step's kernels and returns:
+ * the caller reads the two floats after an event it records on `stream` has completed (engine_for_cyclical.py:164,186
+ * sync twice per step instead).  A step whose loss or gradient norm is not finite leaves the weights untouched, and so
+ * does every later step of that engine. */
+int uvit_engine_read_stats_async(uvit_engine* e, float* host_out2, uvit_stream stream);
 /* copies {loss, grad_norm} to host memory; synchronises the stream */
 int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_stream stream);
 
@@ -239,6 +252,11 @@ int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* c
 int uvit_op_target_finalize(float* acc, const int32_t* count, int n_layers, int post_ln, int Mmax, int C, float eps,
                             uvit_stream stream);
 int uvit_op_mask_compact(const int64_t* mask, int32_t* rowidx, int32_t* count, int B, int P, uvit_stream stream);
+/* Synthetic batch built on the device (the loader contract of datasets.py:110-118 / engine_for_cyclical.py:45,58): images
+ * (B, chans, S, S) f32 ~ N(0, 1); mask (B, patches) int64 with exactly n_mask ones per image.  Counter-based on (seed, it).
+ * Either pointer may be NULL. */
+int uvit_op_synth_batch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,
+                        uint32_t it, uvit_stream stream);
 int uvit_op_im2col(const float* img, void* cols_bf16, int B, int Cin, int img_size, int patch, uvit_stream stream);
 int uvit_op_droppath(float* scales, const float* rates_dev, int depth, int B, uint32_t seed, uint32_t step,
                      uvit_stream stream);

@@ -30,7 +30,10 @@ def main():
     x = closed_form_images("ddp", B, 48)
     mask = exact_masks(B, 9, 4, 77)
     per = B // world
-    lo = 0 if dropout else rank * per
+    if dropout:
+        lo, per = 0, 4                      # every rank (and the 1-rank run) sees the same four images
+    else:
+        lo = rank * per
     xs, ms = x[lo:lo + per].cuda(), mask[lo:lo + per].cuda()
     model, _ = native_model(cfg)
     ema, opt = native_trainer(model)

@@ -65,7 +65,7 @@ def nt(L, mode, a, w, M, N, K, lda, ldw, ep, stream, tail=None):
 
 
 def tn(L, y, x, M, N, K, ldy, ldx, out, ldc, stream):
-    return tn(L, y, x, M, N, K, ldy, ldx, out, ldc, _tune_ref(), stream)
+    return L.uvit_op_gemm_tn(y, x, M, N, K, ldy, ldx, out, ldc, _tune_ref(), stream)
 
 
 def epi(**kw):
@@ -97,7 +97,7 @@ def test_gemm_nt_bias_bf16_and_f32(L, M, N, K):
     close(out32, ref, rtol=2e-3, atol=2e-3, what="f32 out")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(25216, 768, 768), (25216, 3072, 768), (2048, 768, 3072), (1100, 2304, 768), (1024, 256, 128), (1024, 256, 64)])
 def test_gemm_nt_large_tile_kernel(L, M, N, K, variant):
     """Shapes that dispatch to the 256x256 deep-prefetch kernel (N % 256 == 0, M >= 1024): parity, a ragged
@@ -115,7 +115,7 @@ def test_gemm_nt_large_tile_kernel(L, M, N, K, variant):
             assert torch.equal(out32, first), "non-deterministic result: LDS pipeline race"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5])
+@pytest.mark.parametrize("variant", [0, 1, 5, 6, 7])
 def test_gemm_nt_large_identity(L, variant):
     """A = [I; I; ...] against an asymmetric W on the large-tile kernels: exact, catches any fragment / quadrant mix-up."""
     K, N, M = 256, 512, 2048
@@ -137,7 +137,8 @@ def test_gemm_nt_asymmetric_identity(L):
     torch.testing.assert_close(out, w.float().t().contiguous(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("variant,nb,tokens,Cd,Pn", [(3, 3, 10, 128, 9), (0, 11, 100, 256, 140), (1, 11, 100, 256, 140), (5, 11, 100, 256, 140)])
+@pytest.mark.parametrize("variant,nb,tokens,Cd,Pn", [(3, 3, 10, 128, 9), (0, 11, 100, 256, 140), (1, 11, 100, 256, 140), (5, 11, 100, 256, 140),
+                                                     (6, 11, 100, 256, 140), (7, 11, 100, 256, 140)])
 def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L, variant, nb, tokens, Cd, Pn):
     """Every fused epilogue, on the 128x128 kernel (small shapes) and on each large-tile variant (ragged M = 1100)."""
     with tuned(nt_variant=variant):
@@ -636,3 +637,30 @@ def test_wasserstein_loss_operator(L, Mrows, count, Cd):
     assert rel_o < 2e-2, f"other rows: relative L2 error {rel_o}"
     if count < Mrows:
         assert torch.all(dc[count:] == 0) and torch.all(dm[count:] == 0)
+
+
+def test_synth_batch_on_device(L):
+    """On-device batch synthesis: masks with EXACTLY n ones per image, bit-exact against a numpy
+    restatement of the kernel's counter-based ranking; images ~ N(0, 1); everything a pure function of (seed, it)."""
+    B, Pn, n_mask, S_ = 16, 196, 120, 224
+    img = torch.zeros(B, 3, S_, S_, device="cuda"); mask = torch.full((B, Pn), 7, dtype=torch.int64, device="cuda")
+    ok(L.uvit_op_synth_batch(P(img), P(mask), B, 3, S_, Pn, n_mask, 1234, 5, S()))
+    m = mask.cpu().numpy()
+    assert ((m == 0) | (m == 1)).all() and (m.sum(1) == n_mask).all()
+    from oracle.closed_form import _mix32
+    with np.errstate(over="ignore"):
+        key = _mix32(np.uint32(1234) ^ np.uint32((5 * 0x9E3779B9 + 0x51ED270B) & 0xFFFFFFFF))
+        keys = _mix32(np.arange(B * Pn, dtype=np.uint32) ^ (key ^ np.uint32(0xA5A5A5A5))).reshape(B, Pn)
+    order = np.argsort(keys, axis=1, kind="stable")
+    ref = np.zeros((B, Pn), dtype=np.int64)
+    np.put_along_axis(ref, order[:, :n_mask], 1, axis=1)
+    assert np.array_equal(m, ref)
+    x = img.float()
+    assert abs(x.mean().item()) < 5e-3 and abs(x.std().item() - 1.0) < 5e-3
+    assert abs((x ** 3).mean().item()) < 2e-2 and abs((x ** 4).mean().item() - 3.0) < 5e-2          # skewness 0, kurtosis 3
+    assert abs(x.view(B, -1)[:, :-1].mul(x.view(B, -1)[:, 1:]).mean().item()) < 5e-3                  # neighbours uncorrelated
+    img2 = torch.zeros_like(img); mask2 = torch.zeros_like(mask)
+    ok(L.uvit_op_synth_batch(P(img2), P(mask2), B, 3, S_, Pn, n_mask, 1234, 5, S()))
+    assert torch.equal(img, img2) and torch.equal(mask, mask2)
+    ok(L.uvit_op_synth_batch(P(img2), P(mask2), B, 3, S_, Pn, n_mask, 1234, 6, S()))
+    assert not torch.equal(img, img2) and not torch.equal(mask, mask2)

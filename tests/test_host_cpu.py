@@ -284,3 +284,25 @@ def test_target_layers_follow_python_list_indexing(native):
     for bad in ([12], [-13], [6, 7, 99]):
         with pytest.raises(IndexError):
             mk(bad)
+
+
+def test_epoch_scalars_follow_the_reference_loop_state(native):
+    """Device schedule table = the per-iteration scalars of engine_for_cyclical.py:41,47-56,182-185, with
+    cur_decay as loop STATE: annealed while it < ema_start_at, then frozen at its last annealed value for the rest of the
+    epoch; 0 / "skip" once it passes start_lr_decay_at_step."""
+    import ctypes
+    from uncertainty_vit_amd.engine_for_cyclical import epoch_scalars
+    from uncertainty_vit_amd.optim_factory import ArenaAdamW
+    f32 = lambda v: ctypes.c_float(float(v)).value  # noqa: E731
+    opt = ArenaAdamW(tiny_model(), 1e-3, 0.05)
+    lr_tab = [1e-4 * (i + 1) for i in range(20)]
+    wd_tab = [0.05 + 0.01 * i for i in range(20)]
+    sc = epoch_scalars(opt, 4, 8, lr_tab, wd_tab, ema_start_at=7, decay_init=0.99, decay=0.9998, start_lr_decay_at_step=9)
+    assert [s[0] for s in sc] == [f32(lr_tab[i]) for i in range(4, 12)] and [s[1] for s in sc] == [f32(wd_tab[i]) for i in range(4, 12)]
+    anneal = lambda it: 0.99 + it * (0.9998 - 0.99) / 7  # noqa: E731
+    assert sc[0][2] == f32(anneal(4)) and sc[2][2] == f32(anneal(6))
+    assert sc[3][2] == f32(anneal(6)) and sc[5][2] == f32(anneal(6))        # it = 7..9: frozen at the last annealed value
+    assert sc[6][2] == -1.0 and sc[7][2] == -1.0                             # it = 10, 11 > start_lr_decay_at_step: EMA skipped
+    flat = epoch_scalars(opt, 0, 3, None, None, 0, 0.99, 0.9998, -1)
+    assert flat == [(f32(1e-3), f32(0.05), f32(0.9998))] * 3
+    assert epoch_scalars(opt, 0, 2, None, None, 0, 1.0, 1.0, -1)[0][2] == -1.0       # decay 1: `cur_decay != 1` is false

@@ -7,13 +7,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uncertainty_vit_amd import native  # noqa: E402
-from uncertainty_vit_amd.native import GemmEpilogue  # noqa: E402
+from uncertainty_vit_amd.native import GemmEpilogue, Tuning  # noqa: E402
 
 L = native.lib()
 S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
 
+TUNE = Tuning.default()          # launch tuning is an argument of every call (no process-wide state)
 COLD = "--cold" in sys.argv      # evict the Infinity Cache between launches: operands come from HBM, as inside the step
 _flush = None
 
@@ -48,18 +49,19 @@ def time_nt(mode, M, N, K, iters=20):
     bias = torch.randn(N, device="cuda")
     gamma = torch.randn(N, device="cuda")
     resid = torch.randn(M, N, device="cuda") if mode == 3 else None
-    aux = torch.randn(M, N, device="cuda").to(torch.bfloat16) if mode == 6 else None
+    aux = torch.randn(M, N, device="cuda").to(torch.bfloat16) if mode in (6, 9) else None
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if mode in (3, 4) else torch.bfloat16)
-    out2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if mode in (2, 3) else None
+    out2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) if mode in (2, 3, 8) else None
     e = GemmEpilogue()
     e.out = out.data_ptr(); e.out2 = out2.data_ptr() if out2 is not None else 0
     e.bias = bias.data_ptr(); e.bias2 = bias.data_ptr(); e.gamma = gamma.data_ptr()
     e.resid = resid.data_ptr() if resid is not None else 0
     e.aux = aux.data_ptr() if aux is not None else 0
     e.ldo, e.tokens, e.patches = N, 197, 196
+    run = lambda: L.uvit_op_gemm_nt_tuned(mode, P(a), P(w), M, N, K, K, K, C.byref(e), C.byref(TUNE), None, S())  # noqa: E731
     for _ in range(3):
-        assert L.uvit_op_gemm_nt(mode, P(a), P(w), M, N, K, K, K, C.byref(e), S()) == 0
-    us = _timed(lambda: L.uvit_op_gemm_nt(mode, P(a), P(w), M, N, K, K, K, C.byref(e), S()), iters)
+        assert run() == 0
+    us = _timed(run, iters)
     return us, 2.0 * M * N * K / us / 1e6
 
 
@@ -67,49 +69,52 @@ def time_tn(M, N, K, iters=20):
     y = (torch.randn(M, N, device="cuda") * 0.1).to(torch.bfloat16)
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     out = torch.zeros(N, K, device="cuda")
+    run = lambda: L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, C.byref(TUNE), S())  # noqa: E731
     for _ in range(3):
-        assert L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()) == 0
-    us = _timed(lambda: L.uvit_op_gemm_tn(P(y), P(x), M, N, K, N, K, P(out), K, S()), iters)
+        assert run() == 0
+    us = _timed(run, iters)
     return us, 2.0 * M * N * K / us / 1e6
 
 
 if __name__ == "__main__" and "bench_gemm" in sys.argv[0]:
     M = 25216
-    names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu"}
+    names = {0: "bf16", 1: "qkv", 2: "gelu", 3: "resid", 4: "f32", 6: "dgelu", 8: "gelu_dg", 9: "mulaux"}
     print("== NT: step shapes, variants 0 (128x128, 2 WG/CU) / 1 (256x256 staggered, 1 WG/CU) ==")
-    for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (3, 768, 3072), (6, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
+    for mode, N, K in ((1, 2304, 768), (3, 768, 768), (2, 3072, 768), (8, 3072, 768), (3, 768, 3072), (9, 3072, 768), (0, 768, 3072), (0, 768, 768), (0, 768, 2304)):
         row = []
-        for v in (0, 1, 5, 3):
-            L.uvit_set_gemm_variant(v)
+        for v in (0, 1, 5, 6, 7, 3):
+            TUNE.nt_variant = v
             us, tf = time_nt(mode, M, N, K)
             row.append(f"{'auto' if v == 3 else 'v%d' % v}: {us:6.1f} us {tf:5.0f} TF")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
-    L.uvit_set_gemm_variant(3)
+    TUNE.nt_variant = 3
+    if "--quick" in sys.argv:
+        sys.exit(0)
     print("== NT: square references ==")
     for n in (4096, 8192):
         row = []
-        for v in (0, 1):
-            L.uvit_set_gemm_variant(v)
+        for v in (0, 1, 6):
+            TUNE.nt_variant = v
             us, tf = time_nt(0, n, n, n, iters=5)
             row.append(f"v{v}: {us:8.1f} us {tf:7.1f} TF/s")
         print(f"{n}^3: " + " | ".join(row))
     print("== NT: K sweep at M=25216 N=3072 ==")
     for K in (128, 256, 768, 1536, 3072):
         row = []
-        for v in (0, 1):
-            L.uvit_set_gemm_variant(v)
+        for v in (0, 1, 6):
+            TUNE.nt_variant = v
             us, tf = time_nt(0, M, 3072, K)
             row.append(f"v{v}: {us:7.1f} us {tf:6.1f} TF/s")
         print(f"K={K:5d}: " + " | ".join(row))
-    L.uvit_set_gemm_variant(3)
+    TUNE.nt_variant = 3
     if "--tn" not in sys.argv:
         sys.exit(0)
     print("== TN (wgrad), split target sweep ==")
     for N, K in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
         row = []
         for tgt in (256, 384, 512, 768, 1024, 1536):
-            L.uvit_set_tn_split_target(tgt)
+            TUNE.tn_split_target = tgt
             us, tf = time_tn(M, N, K)
             row.append(f"{tgt}: {us:6.1f}us {tf:5.0f}TF")
         print(f"wgrad N={N:5d} K={K:5d}: " + " | ".join(row))
-    L.uvit_set_tn_split_target(512)
+    TUNE.tn_split_target = 512

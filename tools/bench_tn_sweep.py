@@ -1,17 +1,17 @@
 """wgrad (TN) GEMM: token-count sweep -> slope (main loop) and intercept (fill + atomics epilogue)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from bench_gemm import time_tn, L  # noqa: E402
+from bench_gemm import time_tn, L, TUNE  # noqa: E402
 
 for N, K in ((3072, 768), (768, 768), (2304, 768), (768, 3072)):
     for v in (0, 1):
-        L.uvit_set_tn_variant(v)
+        TUNE.tn_variant = v
         row = []
         for M in (6400, 12608, 25216, 50432):
             us, tf = time_tn(M, N, K)
             row.append(f"M={M}: {us:6.1f}us {tf:5.0f}TF")
         print(f"N={N:5d} K={K:5d} variant {v}: " + " | ".join(row))
-L.uvit_set_tn_variant(3)
+TUNE.tn_variant = 3
 
 # the four wgrads of one ViT-B layer: separate launches (best variant each) vs the grouped launch
 import ctypes as C
@@ -45,17 +45,17 @@ def timed(fn, iters=10):
 
 def separate():
     for (y, x, out, b), (m, n, k) in zip(bufs, specs):
-        L.uvit_op_gemm_tn(P(y), P(x), m, n, k, n, k, P(out), k, S())
+        L.uvit_op_gemm_tn(P(y), P(x), m, n, k, n, k, P(out), k, C.byref(TUNE), S())
 
 
 flops = sum(2.0 * m * n * k for m, n, k in specs)
 for v in (0, 1):
-    L.uvit_set_tn_variant(v)
+    TUNE.tn_variant = v
     us = timed(separate)
     print(f"layer wgrads, 4 launches, variant {v}: {us:7.1f} us  {flops / us / 1e6:6.0f} TF/s")
-L.uvit_set_tn_variant(3)
+TUNE.tn_variant = 3
 for ch in (0, 1, 2, 3, 5, 7, 10, 14):
-    L.uvit_set_wgrad_group_chunks(ch)
-    us = timed(lambda: L.uvit_op_wgrad_group(probs, 4, S()))
+    TUNE.wgrad_group_chunks = ch
+    us = timed(lambda: L.uvit_op_wgrad_group(probs, 4, C.byref(TUNE), S()))
     print(f"layer wgrads, grouped, chunks {ch:2d}: {us:7.1f} us  {flops / us / 1e6:6.0f} TF/s")
-L.uvit_set_wgrad_group_chunks(0)
+TUNE.wgrad_group_chunks = 0

@@ -382,11 +382,11 @@ int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int n
 // A rank whose loss is not finite puts a NaN into its gradient arena BEFORE the all-reduce: the SUM carries it to every
 // rank, so all ranks see a non-finite gradient norm, skip AdamW / EMA (optim.hip) and stop together (the reference's
 // rank-local exit at engine_for_cyclical.py:166-168 would leave the peers blocked in the next collective).
-__global__ void poison_kernel(const float* __restrict__ loss, float* __restrict__ dst) {
-    if ((__float_as_uint(*loss) & 0x7F800000u) == 0x7F800000u) *dst = __int_as_float(0x7FC00000);
+__global__ void poison_kernel(const float* __restrict__ loss, float* __restrict__ dst, int* __restrict__ sticky) {
+    if ((__float_as_uint(*loss) & 0x7F800000u) == 0x7F800000u) { *dst = __int_as_float(0x7FC00000); if (sticky) *sticky = 1; }
 }
-int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(poison_kernel, dim3(1), dim3(1), 0, s, loss, dst);
+int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, int* sticky, hipStream_t s) {
+    hipLaunchKernelGGL(poison_kernel, dim3(1), dim3(1), 0, s, loss, dst, sticky);
     return uvit_check_launch();
 }
 
@@ -471,5 +471,54 @@ int uvit_wasserstein_loss_launch(const float* out_m, const float* out_c, const f
     hipLaunchKernelGGL(wl_sum_kernel, dim3(64), dim3(256), 0, s, count, scratch, Mmax);
     hipLaunchKernelGGL(wl_grad_kernel, dim3((Mmax + 3) / 4), dim3(256), 0, s, out_m, out_c, tgt_m, tgt_c, count, scratch,
                        lam * loss_scale, loss, (bf16*)dout_m, (bf16*)dout_c, Mmax, C);
+    return uvit_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// On-device synthetic batch: the loader contract of datasets.py:110-118 produced where it is
+// consumed -- images (B, Cin, S, S) f32 ~ N(0, 1) (post-Normalize statistics) and bool_masked_pos (B, P) int64 with
+// EXACTLY n_mask ones per image (a uniformly random subset) -- so a benchmark / soak run needs no host loader and no
+// PCIe traffic.  Counter-based: element i of step `it` depends only on (seed, it, i).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void synth_images_kernel(float* __restrict__ img, size_t n2, uint32_t key) {
+    // two normals per pair of uniforms (Box-Muller); n2 = number of float2 pairs
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t a = uvit_hash32((uint32_t)(2 * i) ^ key), b = uvit_hash32((uint32_t)(2 * i + 1) ^ key ^ (uint32_t)(i >> 31));
+        const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1)
+        const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        ((float2*)img)[i] = make_float2(r * cs, r * sn);
+    }
+}
+
+// one workgroup per image: patch i is masked when its key ranks among the n_mask smallest of the image's P keys
+__global__ __launch_bounds__(256)
+void synth_mask_kernel(int64_t* __restrict__ mask, int P, int n_mask, uint32_t key) {
+    extern __shared__ uint32_t keys[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = uvit_hash32((uint32_t)(b * P + i) ^ key);
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const uint32_t k = keys[i];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) rank += (keys[j] < k) || (keys[j] == k && j < i);
+        mask[(size_t)b * P + i] = rank < n_mask ? 1 : 0;
+    }
+}
+
+int uvit_synth_batch_launch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,
+                            uint32_t it, hipStream_t s) {
+    if (B < 1 || chans < 1 || img_size < 1 || patches < 1 || n_mask < 0 || n_mask > patches) return UVIT_ERR_SHAPE;
+    const size_t n = (size_t)B * chans * img_size * img_size;
+    if (n % 2) return UVIT_ERR_SHAPE;
+    const uint32_t key = uvit_hash32(seed ^ (it * 0x9E3779B9u + 0x51ED270Bu));
+    if (images) {
+        size_t g = (n / 2 + 255) / 256;
+        hipLaunchKernelGGL(synth_images_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, images, n / 2, key);
+    }
+    if (mask) hipLaunchKernelGGL(synth_mask_kernel, dim3(B), dim3(256), patches * sizeof(uint32_t), s, mask, patches, n_mask, key ^ 0xA5A5A5A5u);
     return uvit_check_launch();
 }

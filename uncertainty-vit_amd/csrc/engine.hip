@@ -152,6 +152,7 @@ struct uvit_engine {
     float *dp_scales, *dp_rates;
     float *loss, *gnorm; double* sumsq;
     float* wl_scratch;     // Wasserstein loss: scalars + per-row distances
+    int* poisoned;         // sticky: set by the first step whose loss / gradient norm is not finite; AdamW and EMA then skip every step
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
     float* grep;           // [NREP][no-decay region] replicated column-sum accumulators
@@ -220,6 +221,7 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->S * e->B); e->dp_rates = b.take<float>(c.depth);
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->wl_scratch = b.take<float>(16 + BPp);
+    e->poisoned = b.take<int>(64);
     e->tdesc = b.take<TransposeDesc>(7 * c.depth + 4);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
     e->grep = b.take<float>((size_t)NREP * e->n_nd);
@@ -241,7 +243,7 @@ static void fill_dims(uvit_engine* e) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             ncu = prop.multiProcessorCount;
         const int nhalf = (e->N + 15) / 16 > 7 ? 2 : 1;
-        const int resident = e->S == 2 ? 1 : 2;       // the two-stream kernel holds four 28-KiB images: one workgroup per CU
+        const int resident = 1;                       // both dQ kernels hold four 28-KiB images (double-buffered K, V): one workgroup per CU
         int max_chunks = (resident * ncu) / (e->H * nhalf);
         if (max_chunks < 1) max_chunks = 1;
         e->chunk = (e->B + max_chunks - 1) / max_chunks;
@@ -357,7 +359,7 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
 
 static int tune_from_abi(const uvit_tuning* t, GemmTune& g) {
     if (!t) { g = GemmTune(); return UVIT_OK; }
-    if ((t->nt_variant != 0 && t->nt_variant != 1 && t->nt_variant != 3 && t->nt_variant != 5) ||
+    if ((t->nt_variant != 0 && t->nt_variant != 1 && t->nt_variant != 3 && t->nt_variant != 5 && t->nt_variant != 6 && t->nt_variant != 7) ||
         (t->tn_variant != 0 && t->tn_variant != 1 && t->tn_variant != 3) || t->tn_split_target < 0 || t->wgrad_group_chunks < 0)
         return UVIT_ERR_ARG;
     g.nt_variant = t->nt_variant; g.tn_variant = t->tn_variant;
@@ -605,10 +607,10 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // against the student forward); their first consumers run after the ev_teacher join below.
     hipStream_t ts = e->dual ? e->aux : s;
     if (e->dual) { HIPCHECK(hipEventRecord(e->ev_fork, s)); HIPCHECK(hipStreamWaitEvent(ts, e->ev_fork, 0)); }
-    HIPCHECK(hipMemsetAsync(e->buf.grads, 0, lo.n_live * sizeof(float), ts));      // frozen tensors never receive a gradient
-    HIPCHECK(hipMemsetAsync(e->grep, 0, (size_t)NREP * e->n_nd * sizeof(float), ts));
-    HIPCHECK(hipMemsetAsync(e->loss, 0, 64 * sizeof(float), ts));
-    HIPCHECK(hipMemsetAsync(e->dXa, 0, e->rows_alloc() * C * sizeof(float), ts));
+    CHECK(uvit_zero_launch(e->buf.grads, lo.n_live * sizeof(float), ts));      // frozen tensors never receive a gradient
+    CHECK(uvit_zero_launch(e->grep, (size_t)NREP * e->n_nd * sizeof(float), ts));
+    CHECK(uvit_zero_launch(e->loss, 64 * sizeof(float), ts));
+    CHECK(uvit_zero_launch(e->dXa, e->rows_alloc() * C * sizeof(float), ts));
     e->slab_started = false; e->ls_prefused = -1;
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
@@ -789,7 +791,7 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed
     // fold the replicated column-sum accumulators into the no-decay gradients
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
-    CHECK(uvit_poison_if_nonfinite_launch(e->loss, g + lo.n_decay, s));     // non-finite loss -> every rank's norm is NaN
+    CHECK(uvit_poison_if_nonfinite_launch(e->loss, g + lo.n_decay, e->poisoned, s));     // non-finite loss -> every rank's norm is NaN
     return UVIT_OK;
 }
 
@@ -802,6 +804,7 @@ extern "C" int uvit_step_wait_layer_grads(uvit_engine* e, int layer, uvit_stream
 
 extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit_stream stream) {
     if (!e || !hp) return UVIT_ERR_ARG;
+    if (hp->sched_dev && (hp->sched_len < 1 || hp->sched_index < 0 || hp->sched_index >= hp->sched_len)) return UVIT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     Layout& lo = e->lo;
     HIPCHECK(hipMemsetAsync(e->sumsq, 0, sizeof(double), s));
@@ -809,9 +812,11 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
     const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;
     CHECK(uvit_adamw_launch(e->buf.params, e->buf.grads, e->buf.adam_m, e->buf.adam_v, e->buf.params_bf16, lo.n_live, lo.n_decay,
                             hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
-                            e->gnorm, s, e->loss));
+                            e->gnorm, s, e->loss, (hp->do_ema || hp->sched_dev) ? e->buf.ema : nullptr, e->buf.ema_bf16, hp->ema_decay, e->poisoned,
+                            hp->sched_dev, hp->sched_len, hp->sched_index));
     CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
-    if (hp->do_ema) CHECK(uvit_ema_launch(e->buf.ema, e->buf.params, e->buf.ema_bf16, lo.n_live, hp->ema_decay, s, e->loss, e->sumsq));
+    // frozen tensors (two-stream cov_qkv.weight) sit behind n_live: AdamW never touches them, the reference's EMA does
+    // average them (ModelEmaV2 walks every state-dict value) -- a no-op on values that never change, skipped
     return UVIT_OK;
 }
 
@@ -821,6 +826,12 @@ extern "C" int uvit_train_step(uvit_engine* e, const float* images, const int64_
     for (int l = e->cfg.depth - 1; l >= 0; --l) CHECK(uvit_step_backward_layer(e, l, hp, stream));
     CHECK(uvit_step_backward_embed(e, stream));
     return uvit_step_update(e, hp, stream);
+}
+
+extern "C" int uvit_engine_read_stats_async(uvit_engine* e, float* host_out2, uvit_stream stream) {
+    if (!e || !host_out2) return UVIT_ERR_ARG;
+    HIPCHECK(hipMemcpyAsync(host_out2, e->loss, 2 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return UVIT_OK;
 }
 
 extern "C" int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_stream stream) {
@@ -939,6 +950,11 @@ extern "C" int uvit_op_target_finalize(float* acc, const int32_t* count, int nl,
 }
 extern "C" int uvit_op_mask_compact(const int64_t* mask, int32_t* rowidx, int32_t* count, int B, int P, uvit_stream st) {
     return uvit_mask_compact_launch(mask, rowidx, count, B, P, S(st));
+}
+extern "C" int uvit_op_synth_batch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,
+                                   uint32_t it, uvit_stream st) {
+    if (!images && !mask) return UVIT_ERR_ARG;
+    return uvit_synth_batch_launch(images, mask, B, chans, img_size, patches, n_mask, seed, it, S(st));
 }
 extern "C" int uvit_op_im2col(const float* img, void* cols, int B, int Cin, int S_, int p, uvit_stream st) {
     return uvit_im2col_launch(img, cols, B, Cin, S_, p, S(st));

@@ -430,7 +430,6 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     const int m0 = tm * BM_, n0 = tn * T_BN;
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
-
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
     // 32-bit element offsets from the (scalar) base pointers keep the loader at LA + LA + 2 + 2 VGPRs
@@ -554,6 +553,128 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     EPI_RUN(MODE, 2 * MT, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
 #undef ACC1
 #undef MB1
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel "R" (ring): (16 MT) x 256 block tile, BK = 32, 4 waves side by side over the 256 columns (each wave: all
+// rows x 64 columns), TWO workgroups per CU.
+//
+// Why it exists: with K = 768 the launches of the step are as much epilogue as main loop (fc1: 310 MB of stores against
+// 61 us of MFMA work), and a one-workgroup-per-CU kernel runs the two back to back -- the MFMA pipe idles while its tile
+// drains at the HBM rate.  Two INDEPENDENT workgroups per CU drift apart by themselves: one streams its finished tile out
+// while the other is in its K loop, with no in-order vmcnt coupling between one's stores and the other's operand loads
+// (CDNA4 counts loads and stores in one queue per wave).  The 128x128 kernel above has the same residency but a
+// one-K-tile prefetch distance and twice the L2 traffic per flop; here the ring holds THREE K-steps (72-80 KB per
+// workgroup: two 32-deep steps in flight behind every wait, never vmcnt(0) in the steady state) and the tile is twice as wide.
+// LDS images are [rows][32 k] (64-B rows, 1 KB = 16 rows per LDS-DMA wave-instruction); 16-B chunk c of row r sits at
+// c ^ F[(r >> 2) & 3], F = {0,2,3,1}: the four 16-lane groups of a ds_read_b128 then each cover all 16 slots of the 256-B
+// bank row (a plain or (r >> 2)-XOR image is 2-way conflicted).  The swizzle is applied to the SOURCE address.
+// ------------------------------------------------------------------------------------------
+#define R_BN 256
+#define R_BK 32
+#define R_THREADS 256
+#define R_STAGES 3
+__host__ __device__ constexpr int r_stage_bytes(int mt) { return (16 * mt + R_BN) * R_BK * 2; }
+__host__ __device__ constexpr int r_lds_bytes(int mt) {
+    return R_STAGES * r_stage_bytes(mt) > 4 * EPI_WAVE_BYTES ? R_STAGES * r_stage_bytes(mt) : 4 * EPI_WAVE_BYTES;
+}
+
+template <int MODE, int MT>
+__global__ __launch_bounds__(R_THREADS, 2)
+void gemm_ntr_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
+                     int lda, int ldw, GemmEpi epi) {
+    constexpr int BM_ = 16 * MT;
+    constexpr int STAGE = r_stage_bytes(MT);
+    constexpr int LA_MAX = (MT + 3) / 4;                 // LDS-DMA instructions per wave for the A image (16 rows each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = N / R_BN, tiles_m = (M + BM_ - 1) / BM_;
+    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
+    int tn0 = 0;
+    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
+    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
+    const int m0 = tm * BM_, n0 = tn * R_BN;
+    const int g = lane >> 4, li = lane & 15;
+    // F = {0, 2, 3, 1} as a 2-bit lookup
+    auto fswz = [](int q) { return (0x78 >> (2 * q)) & 3; };          // 0b01'11'10'00
+
+    // ---- loader: instruction covers 16 rows; lane -> (row = lane >> 2, physical chunk = lane & 3)
+    const int lrow = lane >> 2;
+    const int lchunk = (lane & 3) ^ fswz((lane >> 4) & 3);            // logical (source) chunk of this lane
+    uint32_t srcA[LA_MAX], srcB[4];
+    const int la = (MT - wave + 3) / 4;                                // A instructions of this wave: row groups wave, wave+4, ...
+#pragma unroll
+    for (int j = 0; j < LA_MAX; ++j) {
+        int r = m0 + (j * 4 + wave) * 16 + lrow; r = r < M ? r : M - 1;
+        srcA[j] = (uint32_t)r * (uint32_t)lda + lchunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = n0 + (j * 4 + wave) * 16 + lrow;                 // N % 256 == 0: always in range
+        srcB[j] = (uint32_t)r * (uint32_t)ldw + lchunk * 8;
+    }
+    const int nk = K / R_BK;
+    auto issue = [&](int t) {
+        char* st = smem + (t % R_STAGES) * STAGE;
+        const uint32_t k0 = (uint32_t)t * R_BK;
+#pragma unroll
+        for (int j = 0; j < LA_MAX; ++j)
+            if (j < la) glds16(A + (srcA[j] + k0), st + (j * 4 + wave) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(W + (srcB[j] + k0), st + BM_ * 64 + (j * 4 + wave) * 1024);
+    };
+    // ---- fragment addresses: lane (g, li) reads row base + li, logical chunk g
+    const int foff = li * 64 + ((g ^ fswz((li >> 2) & 3)) << 4);
+    const int boff = BM_ * 64 + wave * 64 * 64 + foff;                  // this wave's 64 W rows (output columns)
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // loads per stage of this wave: la + 4.  The counted wait before K-step t leaves the next stage's loads in flight.
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) { if (la == LA_MAX) { if constexpr (LA_MAX == 2) VM_WAIT(6); else VM_WAIT(7); }
+                          else { if constexpr (LA_MAX == 2) VM_WAIT(5); else VM_WAIT(6); } }
+        else VM_WAIT(0);
+        RAW_BARRIER();                                     // stage t landed for every wave; stage t-1 is no longer read
+        if (t + 2 < nk) issue(t + 2);                      // refills the slot of stage t-1
+        const char* st = smem + (t % R_STAGES) * STAGE;
+        bf16x8 wf[4], af[MT];
+        constexpr int H1 = MT / 2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(st + boff + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < H1; ++mt) af[mt] = *(const bf16x8*)(st + foff + mt * 1024);
+        LDS_WAIT();
+        // the second half of the A fragments is read under the first half's MFMAs
+#pragma unroll
+        for (int mt = H1; mt < MT; ++mt) af[mt] = *(const bf16x8*)(st + foff + mt * 1024);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < H1; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        LDS_WAIT();
+#pragma unroll
+        for (int mt = H1; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();                                       // every wave is done reading the ring: reuse it for staging
+#define ACCR(b, ct) acc[b][ct]
+#define MBR(b) (m0 + (b) * 16)
+    EPI_RUN(MODE, MT, smem + wave * EPI_WAVE_BYTES, n0 + wave * 64, ACCR, MBR);
+#undef ACCR
+#undef MBR
 }
 
 // ------------------------------------------------------------------------------------------
@@ -951,6 +1072,10 @@ static void gemm_init_impl() {
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS_BYTES); } while (0)
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU); ALLOW256(EPI_GELU_DG); ALLOW256(EPI_MULAUX);
 #undef ALLOW256
+#define ALLOWR(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, r_lds_bytes(8)); \
+        (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<MODE, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, r_lds_bytes(10)); } while (0)
+    ALLOWR(EPI_BF16); ALLOWR(EPI_QKV); ALLOWR(EPI_GELU); ALLOWR(EPI_RESID); ALLOWR(EPI_F32); ALLOWR(EPI_PATCH); ALLOWR(EPI_DGELU); ALLOWR(EPI_QKV_ELU); ALLOWR(EPI_GELU_DG); ALLOWR(EPI_MULAUX);
+#undef ALLOWR
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_tn256_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
@@ -980,6 +1105,32 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
                           (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;     // 32-bit operand offsets
     int variant = shape_ok ? nt_variant : 0;
     int mt = 4;
+    // ring kernel (2 workgroups per CU): 6 = 128-row tiles, 7 = 160-row tiles
+    const bool ring_ok = (N % R_BN) == 0 && M >= 128 && K >= 64 && (K % R_BK) == 0 &&
+                         (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;
+    if ((nt_variant == 6 || nt_variant == 7) && ring_ok) {
+        const int rmt = nt_variant == 6 ? 8 : 10;
+        const int rgrid = ((M + 16 * rmt - 1) / (16 * rmt)) * (N / R_BN);
+        const bf16* a_ = (const bf16*)A; const bf16* w_ = (const bf16*)W;
+#define LR(MODE) do { if (rmt == 8) hipLaunchKernelGGL((gemm_ntr_kernel<MODE, 8>), dim3(rgrid), dim3(R_THREADS), r_lds_bytes(8), s, a_, w_, M, N, K, lda, ldw, *epi); \
+        else hipLaunchKernelGGL((gemm_ntr_kernel<MODE, 10>), dim3(rgrid), dim3(R_THREADS), r_lds_bytes(10), s, a_, w_, M, N, K, lda, ldw, *epi); } while (0)
+        switch (mode) {
+            case EPI_BF16: LR(EPI_BF16); break;
+            case EPI_QKV: if (N % 3) return UVIT_ERR_SHAPE; LR(EPI_QKV); break;
+            case EPI_GELU: LR(EPI_GELU); break;
+            case EPI_RESID: LR(EPI_RESID); break;
+            case EPI_F32: LR(EPI_F32); break;
+            case EPI_PATCH: LR(EPI_PATCH); break;
+            case EPI_DGELU: LR(EPI_DGELU); break;
+            case EPI_GELU_DG: LR(EPI_GELU_DG); break;
+            case EPI_MULAUX: LR(EPI_MULAUX); break;
+            case EPI_QKV_ELU: if (N % 3) return UVIT_ERR_SHAPE; LR(EPI_QKV_ELU); break;
+            default: return UVIT_ERR_ARG;
+        }
+#undef LR
+        return uvit_check_launch();
+    }
+    if (variant == 6 || variant == 7) variant = 3;          // shape not supported by the ring kernel: auto
     if (variant == 5) { variant = 1; mt = 5; }
     else if (variant == 3) {
         variant = 1;

@@ -80,58 +80,99 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
 }
 
 // dx = dres + rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += dy*xhat;  db += dy
-// rows per block are chosen by the launcher so that the grid is one balanced wave of resident blocks (25216 rows in
-// fixed 32-row blocks gave 788 blocks on 256 CUs x 4 resident: CUs with 4 blocks set the time, 30 % above the mean)
 // LS = true fuses the LayerScale + DropPath backward of the branch that consumes dx next (modeling_finetune.py:295-298):
 // with e = dx * dp[row / tokens]:  dy_next = bf16(e * gamma),  dgamma += e * y_next,  dbias += dy_next  -- the fp32
 // residual gradient is then not read a second time by a separate pass.
+//
+// Shape of the launch (round 2): ONE 8-wave workgroup per CU walks a contiguous slab of rows.
+//   * every operand row of a wave's NEXT row (x, dy, dres, y_next: 9 KB) is requested before the current row's two wave
+//     reductions, so 2 rows x 8 waves = 144 KB are in flight per CU and the reductions / stores of one row hide under the
+//     loads of the next (the old kernel asked for dres / y_next only after the reductions);
+//   * the column sums (dw, db, dgamma, dbias) are reduced across the 8 waves in LDS and leave as ONE atomic per column
+//     per workgroup: ~250 x 4 x C atomics per launch instead of ~900 x 4 x C (the old 4-wave blocks), 8 adders per
+//     replica address instead of 28 -- same-address float atomics run at a fraction of the streaming rate
+//     (MI355X_MICROARCH.md, Global float atomics), and they were a large part of this kernel's 108 us.
 struct LsNext {
     const bf16* y; const float* gamma; const float* rowscale; bf16* dy; float* dgamma; float* dbias; int tokens;
 };
+#define LNB_WAVES 8
+
 template <int NV, bool LS>
-__global__ __launch_bounds__(LN_WAVES * 64)
+struct LnbRow {                      // operands of one row, as loaded
+    float4 x[NV], dres[NV];
+    bf16x4 dy[NV], y[LS ? NV : 1];
+    float mean, rstd, dp;
+    int xr;
+};
+
+template <int NV, bool LS>
+__device__ __forceinline__ void lnb_load(LnbRow<NV, LS>& r, int row, const bf16* dy, const float* x, const int* rowidx,
+                                         const float* mean_i, const float* rstd_i, const float* dres, const LsNext& ls,
+                                         int C, int nv, int lane) {
+    const int xr = rowidx ? rowidx[row] : row;
+    r.xr = xr;
+    r.mean = mean_i[row]; r.rstd = rstd_i[row];
+    r.dp = 1.0f;
+    if constexpr (LS) { if (ls.rowscale) r.dp = ls.rowscale[xr / ls.tokens]; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            r.x[k] = ((const float4*)(x + (size_t)xr * C))[i];
+            r.dy[k] = ((const bf16x4*)(dy + (size_t)row * C))[i];
+            r.dres[k] = dres ? ((const float4*)(dres + (size_t)xr * C))[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (LS) r.y[k] = ((const bf16x4*)(ls.y + (size_t)xr * C))[i];
+        }
+    }
+}
+
+template <int NV, bool LS>
+__global__ __launch_bounds__(LNB_WAVES * 64)
 void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ rowidx,
                    const int* __restrict__ count, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                    const float* __restrict__ w, const float* __restrict__ dres, float* __restrict__ dx,
                    float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep, size_t rep_stride, LsNext ls,
                    int rows_per_block) {
-    __shared__ float red[2][LN_WAVES][64 * 4];
-    // column sums go to replica (block % nrep): spreads same-address atomic contention (summed once per step)
-    dw += (size_t)(blockIdx.x % nrep) * rep_stride; db += (size_t)(blockIdx.x % nrep) * rep_stride;
+    __shared__ float red[LNB_WAVES][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
     const int n_valid = count ? min(*count, M) : M;
+    float4 ww[NV], gm[LS ? NV : 1];
     RowVec<NV> aw, ab;
     RowVec<LS ? NV : 1> ag, ay;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; }
+    for (int k = 0; k < NV; ++k) {
+        aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k];
+        ww[k] = lane + 64 * k < nv ? ((const float4*)w)[lane + 64 * k] : aw.v[k];
+    }
 #pragma unroll
-    for (int k = 0; k < (LS ? NV : 1); ++k) { ag.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ay.v[k] = ag.v[k]; }
+    for (int k = 0; k < (LS ? NV : 1); ++k) {
+        ag.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ay.v[k] = ag.v[k]; gm[k] = ag.v[k];
+        if constexpr (LS) { if (lane + 64 * k < nv) gm[k] = ((const float4*)ls.gamma)[lane + 64 * k]; }
+    }
     const int row_end = min((int)(blockIdx.x + 1) * rows_per_block, n_valid);
-    for (int row = blockIdx.x * rows_per_block + wave; row < row_end; row += LN_WAVES) {
-        const int xr = rowidx ? rowidx[row] : row;
-        RowVec<NV> r;
-        load_row(r, x + (size_t)xr * C, C, lane);
-        const float mean = mean_i[row], rstd = rstd_i[row];
-        float4 g[NV];
+    int row = blockIdx.x * rows_per_block + wave;
+    LnbRow<NV, LS> cur, nxt;
+    if (row < row_end) lnb_load<NV, LS>(cur, row, dy, x, rowidx, mean_i, rstd_i, dres, ls, C, nv, lane);
+    for (; row < row_end; row += LNB_WAVES) {
+        const bool more = row + LNB_WAVES < row_end;
+        if (more) lnb_load<NV, LS>(nxt, row + LNB_WAVES, dy, x, rowidx, mean_i, rstd_i, dres, ls, C, nv, lane);
+        const float mean = cur.mean, rstd = cur.rstd;
+        float4 g[NV], h[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int i = lane + 64 * k;
-            if (i < nv) {
-                const bf16x4 d = ((const bf16x4*)(dy + (size_t)row * C))[i];
-                const float4 ww = ((const float4*)w)[i];
-                const float d0 = bf2f(d[0]), d1 = bf2f(d[1]), d2 = bf2f(d[2]), d3 = bf2f(d[3]);
-                const float h0 = (r.v[k].x - mean) * rstd, h1 = (r.v[k].y - mean) * rstd,
-                            h2 = (r.v[k].z - mean) * rstd, h3 = (r.v[k].w - mean) * rstd;
-                aw.v[k].x += d0 * h0; aw.v[k].y += d1 * h1; aw.v[k].z += d2 * h2; aw.v[k].w += d3 * h3;
+            if (lane + 64 * k < nv) {
+                const float d0 = bf2f(cur.dy[k][0]), d1 = bf2f(cur.dy[k][1]), d2 = bf2f(cur.dy[k][2]), d3 = bf2f(cur.dy[k][3]);
+                h[k] = make_float4((cur.x[k].x - mean) * rstd, (cur.x[k].y - mean) * rstd, (cur.x[k].z - mean) * rstd,
+                                   (cur.x[k].w - mean) * rstd);
+                aw.v[k].x += d0 * h[k].x; aw.v[k].y += d1 * h[k].y; aw.v[k].z += d2 * h[k].z; aw.v[k].w += d3 * h[k].w;
                 ab.v[k].x += d0; ab.v[k].y += d1; ab.v[k].z += d2; ab.v[k].w += d3;
-                g[k] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
+                g[k] = make_float4(d0 * ww[k].x, d1 * ww[k].y, d2 * ww[k].z, d3 * ww[k].w);
                 s1 += g[k].x + g[k].y + g[k].z + g[k].w;
-                s2 += g[k].x * h0 + g[k].y * h1 + g[k].z * h2 + g[k].w * h3;
-                r.v[k] = make_float4(h0, h1, h2, h3);
+                s2 += g[k].x * h[k].x + g[k].y * h[k].y + g[k].z * h[k].z + g[k].w * h[k].w;
             } else {
-                g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                g[k] = make_float4(0.f, 0.f, 0.f, 0.f); h[k] = g[k];
             }
         }
         s1 = wave_sum(s1) / C;
@@ -140,79 +181,44 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
         for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
-                float4 o = make_float4(rstd * (g[k].x - s1 - r.v[k].x * s2), rstd * (g[k].y - s1 - r.v[k].y * s2),
-                                       rstd * (g[k].z - s1 - r.v[k].z * s2), rstd * (g[k].w - s1 - r.v[k].w * s2));
-                if (dres) {
-                    const float4 d = ((const float4*)(dres + (size_t)xr * C))[i];
-                    o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
-                }
-                ((float4*)(dx + (size_t)xr * C))[i] = o;
+                const float4 o = make_float4(cur.dres[k].x + rstd * (g[k].x - s1 - h[k].x * s2), cur.dres[k].y + rstd * (g[k].y - s1 - h[k].y * s2),
+                                             cur.dres[k].z + rstd * (g[k].z - s1 - h[k].z * s2), cur.dres[k].w + rstd * (g[k].w - s1 - h[k].w * s2));
+                ((float4*)(dx + (size_t)cur.xr * C))[i] = o;
                 if constexpr (LS) {
-                    const float dp = ls.rowscale ? ls.rowscale[xr / ls.tokens] : 1.0f;
-                    const float4 gm = ((const float4*)ls.gamma)[i];
-                    const bf16x4 yy = ((const bf16x4*)(ls.y + (size_t)xr * C))[i];
-                    const float e0 = o.x * dp, e1 = o.y * dp, e2 = o.z * dp, e3 = o.w * dp;
-                    ag.v[k].x += e0 * bf2f(yy[0]); ag.v[k].y += e1 * bf2f(yy[1]); ag.v[k].z += e2 * bf2f(yy[2]); ag.v[k].w += e3 * bf2f(yy[3]);
-                    const bf16x4 ob = {f2bf(e0 * gm.x), f2bf(e1 * gm.y), f2bf(e2 * gm.z), f2bf(e3 * gm.w)};
-                    ((bf16x4*)(ls.dy + (size_t)xr * C))[i] = ob;
+                    const float e0 = o.x * cur.dp, e1 = o.y * cur.dp, e2 = o.z * cur.dp, e3 = o.w * cur.dp;
+                    ag.v[k].x += e0 * bf2f(cur.y[k][0]); ag.v[k].y += e1 * bf2f(cur.y[k][1]);
+                    ag.v[k].z += e2 * bf2f(cur.y[k][2]); ag.v[k].w += e3 * bf2f(cur.y[k][3]);
+                    const bf16x4 ob = {f2bf(e0 * gm[k].x), f2bf(e1 * gm[k].y), f2bf(e2 * gm[k].z), f2bf(e3 * gm[k].w)};
+                    ((bf16x4*)(ls.dy + (size_t)cur.xr * C))[i] = ob;
                     ay.v[k].x += bf2f(ob[0]); ay.v[k].y += bf2f(ob[1]); ay.v[k].z += bf2f(ob[2]); ay.v[k].w += bf2f(ob[3]);
                 }
             }
         }
+        if (more) cur = nxt;
     }
-    // cross-wave reduction of the column partials, then one atomic per column per block
-    if constexpr (LS) {
-        float* dgm = ls.dgamma + (size_t)(blockIdx.x % nrep) * rep_stride;
-        float* dbs = ls.dbias + (size_t)(blockIdx.x % nrep) * rep_stride;
+    // cross-wave reduction of the column partials in LDS, then one atomic per column per workgroup, into replica
+    // (block % nrep) of the accumulators (summed once per step)
+    const size_t rep = (size_t)(blockIdx.x % nrep) * rep_stride;
+    auto fold = [&](const float4& part, float* dst, int k) {
+        __syncthreads();
+        ((float4*)red[wave])[lane] = part;
+        __syncthreads();
+        // 8 waves x 256 floats -> wave q folds floats [32 q, 32 q + 32) of the 256 (lanes 0..31), 8 partial rows each
+        if (lane < 32) {
+            const int col = wave * 32 + lane;
+            float sum = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (64 * k < nv) {
-                __syncthreads();
-                ((float4*)red[0][wave])[lane] = ag.v[k];
-                ((float4*)red[1][wave])[lane] = ay.v[k];
-                __syncthreads();
-                if (wave == 0) {
-                    float4 sg = ((float4*)red[0][0])[lane], sy = ((float4*)red[1][0])[lane];
-#pragma unroll
-                    for (int q = 1; q < LN_WAVES; ++q) {
-                        const float4 a = ((float4*)red[0][q])[lane], c = ((float4*)red[1][q])[lane];
-                        sg.x += a.x; sg.y += a.y; sg.z += a.z; sg.w += a.w;
-                        sy.x += c.x; sy.y += c.y; sy.z += c.z; sy.w += c.w;
-                    }
-                    const int i = lane + 64 * k;
-                    if (i < nv) {
-                        atomicAdd(dgm + 4 * i + 0, sg.x); atomicAdd(dgm + 4 * i + 1, sg.y);
-                        atomicAdd(dgm + 4 * i + 2, sg.z); atomicAdd(dgm + 4 * i + 3, sg.w);
-                        atomicAdd(dbs + 4 * i + 0, sy.x); atomicAdd(dbs + 4 * i + 1, sy.y);
-                        atomicAdd(dbs + 4 * i + 2, sy.z); atomicAdd(dbs + 4 * i + 3, sy.w);
-                    }
-                }
-            }
+            for (int q = 0; q < LNB_WAVES; ++q) sum += red[q][col];
+            const int c = 256 * k + col;                 // column of the row: float4 index (lane' + 64 k) * 4 + component
+            if (c < C) atomicAdd(dst + rep + c, sum);
         }
-    }
+    };
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (64 * k < nv) {
-            __syncthreads();
-            ((float4*)red[0][wave])[lane] = aw.v[k];
-            ((float4*)red[1][wave])[lane] = ab.v[k];
-            __syncthreads();
-            if (wave == 0) {
-                float4 sw = ((float4*)red[0][0])[lane], sb = ((float4*)red[1][0])[lane];
-#pragma unroll
-                for (int q = 1; q < LN_WAVES; ++q) {
-                    const float4 a = ((float4*)red[0][q])[lane], c = ((float4*)red[1][q])[lane];
-                    sw.x += a.x; sw.y += a.y; sw.z += a.z; sw.w += a.w;
-                    sb.x += c.x; sb.y += c.y; sb.z += c.z; sb.w += c.w;
-                }
-                const int i = lane + 64 * k;
-                if (i < nv) {
-                    atomicAdd(dw + 4 * i + 0, sw.x); atomicAdd(dw + 4 * i + 1, sw.y);
-                    atomicAdd(dw + 4 * i + 2, sw.z); atomicAdd(dw + 4 * i + 3, sw.w);
-                    atomicAdd(db + 4 * i + 0, sb.x); atomicAdd(db + 4 * i + 1, sb.y);
-                    atomicAdd(db + 4 * i + 2, sb.z); atomicAdd(db + 4 * i + 3, sb.w);
-                }
-            }
+            fold(aw.v[k], dw, k);
+            fold(ab.v[k], db, k);
+            if constexpr (LS) { fold(ag.v[k], ls.dgamma, k); fold(ay.v[k], ls.dbias, k); }
         }
     }
 }
@@ -282,6 +288,7 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
 
 static int lnb_rows(int M, int resident_blocks_per_cu) {
+    // rows per workgroup so that the grid is `resident_blocks_per_cu` balanced workgroups per CU
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t prop;
@@ -290,8 +297,8 @@ static int lnb_rows(int M, int resident_blocks_per_cu) {
     }
     const int target = ncu * resident_blocks_per_cu;
     int rows = (M + target - 1) / target;
-    rows = ((rows + LN_WAVES - 1) / LN_WAVES) * LN_WAVES;      // every wave of a block walks the same number of rows
-    return rows < 2 * LN_WAVES ? 2 * LN_WAVES : rows;
+    rows = ((rows + LNB_WAVES - 1) / LNB_WAVES) * LNB_WAVES;      // every wave of a block walks the same number of rows
+    return rows < LNB_WAVES ? LNB_WAVES : rows;
 }
 
 static int ln_shape_ok(int M, int C) { return (M > 0 && C > 0 && (C % 4) == 0 && C <= LN_MAXV * 256) ? UVIT_OK : UVIT_ERR_SHAPE; }
@@ -313,8 +320,8 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    const int rpb = lnb_rows(M, 5);
-    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+    const int rpb = lnb_rows(M, 1);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{}, rpb);
     return uvit_check_launch();
 }
@@ -324,8 +331,8 @@ int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, con
                           int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C) || tokens <= 0) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
-    const int rpb = lnb_rows(M, 4);
-    LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+    const int rpb = lnb_rows(M, 1);
+    LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
     return uvit_check_launch();
 }
@@ -333,8 +340,8 @@ int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx
                                const float* rstd, const float* w, float* dx, float* dw, float* db, int Mmax, int C,
                                int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    const int rpb = lnb_rows(Mmax, 5);
-    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((Mmax + rpb - 1) / rpb), dim3(LN_WAVES * 64), 0, s, (const bf16*)dy, x,
+    const int rpb = lnb_rows(Mmax, 1);
+    LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((Mmax + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        rowidx, count, mean, rstd, w, (const float*)nullptr, dx, dw, db, Mmax, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{}, rpb);
     return uvit_check_launch();
 }

@@ -52,14 +52,27 @@ __global__ __launch_bounds__(256)
 void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                   bf16* __restrict__ pb, size_t n4, size_t n4_decay, float lr, float wd, float b1, float b2, float eps,
                   float bc1, float bc2_sqrt, const double* __restrict__ sumsq, float max_norm, float grad_scale,
-                  float* __restrict__ gnorm_out, const float* __restrict__ guard_loss) {
+                  float* __restrict__ gnorm_out, const float* __restrict__ guard_loss,
+                  float* __restrict__ ema, bf16* __restrict__ ema_b, float ema_d, int* __restrict__ sticky,
+                  const float* __restrict__ sched, int sched_len, int sched_idx) {
+    if (sched) {           // device-resident schedules: {lr, weight_decay, ema_decay (< 0: skip)} of this iteration
+        lr = sched[sched_idx]; wd = sched[sched_len + sched_idx]; ema_d = sched[2 * sched_len + sched_idx];
+        if (ema_d < 0.f) ema = nullptr;
+    }
+    // ema != nullptr: the EMA teacher update e <- d e + (1 - d) p_new (engine_for_cyclical.py:182-185) rides in the same pass:
+    // the new weights are in registers, so the separate EMA kernel's second read of the 345 MB parameter arena disappears
     float coef = grad_scale;
     if (sumsq) {
         const float norm = (float)sqrt(*sumsq) * grad_scale;
         if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = norm;
         if (max_norm > 0.f) coef *= fminf(max_norm / (norm + 1e-6f), 1.0f);
     }
-    if (step_poisoned(guard_loss, sumsq)) return;
+    // sticky: the host learns of a poisoned step one step late (asynchronous metrics) and has the next step enqueued by
+    // then -- that step, and any later one, must not move the weights either
+    if (step_poisoned(guard_loss, sumsq) || (sticky && *sticky)) {
+        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
     const float step_size = lr / bc1;
     const float decay = 1.0f - lr * wd;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -78,7 +91,21 @@ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
         pp.w -= step_size * mm.w / (sqrtf(vv.w) / bc2_sqrt + eps);
         ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
         if (pb) { bf16x4 o = {f2bf(pp.x), f2bf(pp.y), f2bf(pp.z), f2bf(pp.w)}; ((bf16x4*)pb)[i] = o; }
+        if (ema) {
+            float4 a = ((const float4*)ema)[i];
+            const float om = 1.0f - ema_d;
+            a.x = ema_d * a.x + om * pp.x; a.y = ema_d * a.y + om * pp.y; a.z = ema_d * a.z + om * pp.z; a.w = ema_d * a.w + om * pp.w;
+            ((float4*)ema)[i] = a;
+            if (ema_b) { bf16x4 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)}; ((bf16x4*)ema_b)[i] = o; }
+        }
     }
+}
+
+// zero fill with 16-B stores: hipMemsetAsync's fill kernel moved the step's 440 MB at 0.8 TB/s (0.53 ms per step)
+__global__ __launch_bounds__(256)
+void zero_kernel(float4* __restrict__ dst, size_t n4) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = z;
 }
 
 __global__ __launch_bounds__(256)
@@ -108,16 +135,23 @@ int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s) {
 }
 int uvit_adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, size_t n_decay, float lr,
                       float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
-                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss) {
+                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss, float* ema, void* ema_bf16,
+                      float ema_decay, int* sticky, const float* sched, int sched_len, int sched_idx) {
     if (n % 4 || n_decay % 4 || step < 1) return UVIT_ERR_SHAPE;
     const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
     const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16*)p_bf16, n / 4, n_decay / 4,
-                       lr, wd, b1, b2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale, gnorm_out, guard_loss);
+                       lr, wd, b1, b2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale, gnorm_out, guard_loss, ema, (bf16*)ema_bf16, ema_decay, sticky, sched, sched_len, sched_idx);
     return uvit_check_launch();
 }
 int uvit_cast_bf16_launch(const float* src, void* dst, size_t n, hipStream_t s) {
     if (n % 4) return UVIT_ERR_SHAPE;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, s, src, (bf16*)dst, n / 4);
+    return uvit_check_launch();
+}
+int uvit_zero_launch(void* dst, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return UVIT_OK;
+    if (((uintptr_t)dst | bytes) & 15) return hipMemsetAsync(dst, 0, bytes, s) == hipSuccess ? UVIT_OK : UVIT_ERR_LAUNCH;
+    hipLaunchKernelGGL(zero_kernel, dim3(stream_grid(bytes / 16)), dim3(256), 0, s, (float4*)dst, bytes / 16);
     return uvit_check_launch();
 }

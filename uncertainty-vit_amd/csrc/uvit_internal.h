@@ -113,7 +113,9 @@ int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf1
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
 int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step,
                          hipStream_t s);
-int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, hipStream_t s);
+int uvit_synth_batch_launch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,
+                            uint32_t it, hipStream_t s);
+int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, int* sticky, hipStream_t s);
 int uvit_wasserstein_loss_launch(const float* out_m, const float* out_c, const float* tgt_m, const float* tgt_c, const int* count,
                                  float lam, float loss_scale, float* scratch, float* loss, void* dout_m_bf16, void* dout_c_bf16,
                                  int Mmax, int C, hipStream_t s);
@@ -125,7 +127,11 @@ int uvit_ema_launch(float* ema, const float* p, void* ema_bf16, size_t n, float 
 int uvit_sumsq_launch(const float* g, size_t n, double* out, hipStream_t s);
 int uvit_adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, size_t n, size_t n_decay, float lr,
                       float wd, float b1, float b2, float eps, int step, const double* sumsq, float max_norm,
-                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss = nullptr);
+                      float grad_scale, float* gnorm_out, hipStream_t s, const float* guard_loss = nullptr,
+                      float* ema = nullptr, void* ema_bf16 = nullptr, float ema_decay = 0.f,    // ema: fused EMA teacher update
+                      int* sticky_poison = nullptr,    // set (and honoured) once a step's loss / norm was not finite
+                      const float* sched_dev = nullptr, int sched_len = 0, int sched_idx = 0);   // device-resident {lr, wd, ema decay} tables
+int uvit_zero_launch(void* dst, size_t bytes, hipStream_t s);
 int uvit_cast_bf16_launch(const float* src, void* dst_bf16, size_t n, hipStream_t s);
 
 struct TransposeDesc { const void* src; void* dst; int rows; int cols; int tile0; int pad; };

@@ -185,6 +185,30 @@ def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_
     return hp
 
 
+def epoch_scalars(optimizer, start_steps, n_iters, lr_schedule_values, wd_schedule_values, ema_start_at, decay_init, decay,
+                  start_lr_decay_at_step):
+    """[(lr, weight_decay, ema_decay or -1 for "skip EMA")] for the n_iters iterations of one epoch, by the sequential rules of
+    engine_for_cyclical.py:41,47-56,182-185 (cur_decay is STATE: it keeps its last annealed value once `it` passes
+    ema_start_at, and stays 0 after the first skipped update).  Values are rounded to float32 as the C ABI carries them."""
+    import ctypes
+    f32 = lambda v: ctypes.c_float(float(v)).value  # noqa: E731
+    g0 = optimizer.param_groups[0]
+    lr, wd = float(g0["lr"]), float(g0["weight_decay"])
+    cur_decay, out = decay, []
+    for it in range(start_steps, start_steps + n_iters):
+        if lr_schedule_values is not None:
+            lr = lr_schedule_values[it] * g0.get("lr_scale", 1.0)
+        if wd_schedule_values is not None and g0["weight_decay"] > 0:
+            wd = wd_schedule_values[it]
+        if it < ema_start_at:
+            cur_decay = decay_init + it * (decay - decay_init) / ema_start_at
+        do_ema = cur_decay != 1 and (start_lr_decay_at_step == -1 or it <= start_lr_decay_at_step)
+        if not do_ema:
+            cur_decay = 0
+        out.append((f32(lr), f32(wd), f32(cur_decay) if do_ema else -1.0))
+    return out
+
+
 def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_start_at, decay_init, decay, target_layers,
                     data_loader: Iterable, optimizer, device: torch.device, epoch: int, loss_scaler,
                     max_norm: float = 0, l1_beta: float = 0.12, log_writer=None, lr_scheduler=None, start_steps=None,
@@ -215,13 +239,58 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     world = utils.get_world_size()
     reducer = None
     engine = None
-    stats = torch.zeros(2, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(2)
+    ring = torch.zeros(4, 2, dtype=torch.float32)
+    events = None
+    if torch.cuda.is_available():
+        ring = ring.pin_memory()
+        events = [torch.cuda.Event() for _ in range(ring.shape[0])]
+    pending = []
     seed = torch.initial_seed()
+
+    def publish(slot, entry):
+        """Meters / TensorBoard of one finished iteration (engine_for_cyclical.py:188-219)."""
+        if events is not None:
+            events[slot].synchronize()
+        loss_value, grad_norm = float(ring[slot, 0]), float(ring[slot, 1])
+        if not (math.isfinite(loss_value) and math.isfinite(grad_norm)):
+            # The reference stops before backward / optimizer.step / EMA (engine_for_cyclical.py:166-168); here the step was
+            # already enqueued, so AdamW and EMA test the device-side loss and (all-reduced) gradient norm themselves and
+            # leave the weights untouched (every later step then sees the same poisoned state and skips too).  The
+            # all-reduced norm is NaN on EVERY rank when any rank's loss was, so all ranks take this exit together instead of
+            # one leaving its peers blocked in the next collective.
+            print("Loss is {}, stopping training".format(loss_value), force=True) if world > 1 else \
+                print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(loss_scale=entry["loss_scale"])
+        metric_logger.update(lr=entry["lr"])
+        metric_logger.update(min_lr=entry["min_lr"])
+        metric_logger.update(loss_var0=0)
+        metric_logger.update(weight_decay=entry["weight_decay"])
+        metric_logger.update(grad_norm=grad_norm)
+        metric_logger.update(cur_decay=entry["cur_decay"])
+        if log_writer is not None:
+            log_writer.update(loss=loss_value, head="loss")
+            log_writer.update(loss_scale=entry["loss_scale"], head="opt")
+            log_writer.update(lr=entry["lr"], head="opt")
+            log_writer.update(min_lr=entry["min_lr"], head="opt")
+            log_writer.update(weight_decay=entry["weight_decay"], head="opt")
+            log_writer.update(grad_norm=grad_norm, head="opt")
+            log_writer.update(cur_decay=entry["cur_decay"], head="cur_decay")
+            log_writer.set_step()
+
+    # Per-iteration scalars of the whole epoch, computed ONCE with the reference's own sequential rules and uploaded as a
+    # device table {lr, weight_decay, ema_decay}[it]: the optimizer kernels index it on the device, so a step's launch
+    # arguments no longer carry iteration-dependent values (SURVEY 8f-3).  The same list feeds the meters.
+    n_iters = len(data_loader) if hasattr(data_loader, "__len__") else None
+    scalars = epoch_scalars(optimizer, start_steps, n_iters, lr_schedule_values, wd_schedule_values, ema_start_at, decay_init,
+                            decay, start_lr_decay_at_step) if n_iters else None
+    sched_dev = None
 
     cur_decay = decay
     for step, (batch, _) in enumerate(metric_logger.log_every(DevicePrefetcher(data_loader, device), print_freq, header)):
         it = start_steps + step  # global training iteration
-        # per-step lr / weight-decay (engine_for_cyclical.py:47-53)
+        # per-step lr / weight-decay (engine_for_cyclical.py:47-53): the param groups keep showing the current values
         if lr_schedule_values is not None or wd_schedule_values is not None:
             for param_group in optimizer.param_groups:
                 if lr_schedule_values is not None:
@@ -250,46 +319,35 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
         hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
                               post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining,
                               depth=net.depth)
+        if scalars is not None and step < len(scalars):
+            assert scalars[step] == (hp.lr, hp.weight_decay, hp.ema_decay if do_ema else -1.0), (scalars[step], hp.lr, hp.weight_decay, hp.ema_decay)
+            if sched_dev is None:
+                sched_dev = torch.tensor([[sc[k] for sc in scalars] for k in range(3)], dtype=torch.float32, device=samples.device)
+            hp.sched_dev, hp.sched_len, hp.sched_index = sched_dev.data_ptr(), len(scalars), step
         native_step(engine, reducer, samples, mask, hp)
         optimizer.step_count += 1
 
-        # one host sync per step, as the reference (loss.item() + torch.cuda.synchronize())
-        check(lib().uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "read_stats")
-        loss_value, grad_norm = float(stats[0]), float(stats[1])
-        if not (math.isfinite(loss_value) and math.isfinite(grad_norm)):
-            # The reference stops before backward / optimizer.step / EMA (engine_for_cyclical.py:166-168); here the step was
-            # already enqueued, so AdamW and EMA test the device-side loss and (all-reduced) gradient norm themselves and
-            # leave the weights untouched.  The all-reduced norm is NaN on EVERY rank when any rank's loss was, so all ranks
-            # take this exit together instead of one leaving its peers blocked in the next collective.
-            print("Loss is {}, stopping training".format(loss_value), force=True) if world > 1 else \
-                print("Loss is {}, stopping training".format(loss_value))
-            sys.exit(1)
-        loss_scale_value = loss_scaler.state_dict()["scale"] if loss_scaler is not None else 1.0
-
-        metric_logger.update(loss=loss_value)
-        metric_logger.update(loss_scale=loss_scale_value)
+        # Metrics leave the device asynchronously: {loss, grad_norm} of this step are copied into a pinned ring slot behind the
+        # step's kernels and read ONE STEP LATE, after the next step has been enqueued -- the host never drains the stream
+        # inside the loop (the reference syncs twice per step: loss.item() and torch.cuda.synchronize(),
+        # engine_for_cyclical.py:164,186).  The host-side scalars of the step travel with the slot so every meter still
+        # receives the values of ONE iteration together.
         lrs = [g["lr"] for g in optimizer.param_groups]
-        metric_logger.update(lr=max(lrs))
-        metric_logger.update(min_lr=min(lrs))
-        metric_logger.update(loss_var0=0)
         wds = [g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0]
-        weight_decay_value = wds[-1] if wds else None
-        metric_logger.update(weight_decay=weight_decay_value)
-        metric_logger.update(grad_norm=grad_norm)
-        metric_logger.update(cur_decay=cur_decay)
-
-        if log_writer is not None:
-            log_writer.update(loss=loss_value, head="loss")
-            log_writer.update(loss_scale=loss_scale_value, head="opt")
-            log_writer.update(lr=max(lrs), head="opt")
-            log_writer.update(min_lr=min(lrs), head="opt")
-            log_writer.update(weight_decay=weight_decay_value, head="opt")
-            log_writer.update(grad_norm=grad_norm, head="opt")
-            log_writer.update(cur_decay=cur_decay, head="cur_decay")
-            log_writer.set_step()
+        entry = dict(lr=max(lrs), min_lr=min(lrs), weight_decay=wds[-1] if wds else None, cur_decay=cur_decay,
+                     loss_scale=loss_scaler.state_dict()["scale"] if loss_scaler is not None else 1.0)
+        slot = step % ring.shape[0]
+        check(lib().uvit_engine_read_stats_async(engine.h, C.c_void_p(ring[slot].data_ptr()), cur_stream()), "read_stats_async")
+        if events is not None:
+            events[slot].record()
+        pending.append((slot, entry))
+        while len(pending) > 1:
+            publish(*pending.pop(0))
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)
 
+    while pending:
+        publish(*pending.pop(0))
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

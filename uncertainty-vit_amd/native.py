@@ -50,7 +50,8 @@ class StepParams(C.Structure):
                 ("l1_beta", C.c_float), ("loss_scale", C.c_float), ("clip_grad", C.c_float), ("lr", C.c_float),
                 ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("opt_step", C.c_int32), ("ema_decay", C.c_float), ("do_ema", C.c_int32), ("grad_scale", C.c_float),
-                ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float)]
+                ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float),
+                ("sched_dev", C.c_void_p), ("sched_len", C.c_int32), ("sched_index", C.c_int32)]
 
 
 class WgradProblem(C.Structure):
@@ -102,6 +103,7 @@ _PROTOTYPES = {
     "uvit_step_update": (_i, [_vp, _vp, _vp]),
     "uvit_train_step": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_engine_read_stats": (_i, [_vp, _vp, _vp]),
+    "uvit_engine_read_stats_async": (_i, [_vp, _vp, _vp]),
     "uvit_tuning_default": (None, [_vp]),
     "uvit_engine_set_tuning": (_i, [_vp, _vp]),
     "uvit_op_wgrad_group": (_i, [_vp, _i, _vp, _vp]),
@@ -128,6 +130,7 @@ _PROTOTYPES = {
     "uvit_op_target_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "uvit_op_mask_compact": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uvit_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "uvit_op_synth_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _u32, _u32, _vp]),
     "uvit_op_droppath": (_i, [_vp, _vp, _i, _i, _u32, _u32, _vp]),
     "uvit_op_cast_bf16": (_i, [_vp, _vp, _i64, _vp]),
 }

@@ -40,8 +40,9 @@ class SmoothedValue:
     median = property(lambda self: float(np.median(np.asarray(self.deque, dtype=np.float64))) if self.deque else 0.0)
     avg = property(lambda self: float(np.mean(np.asarray(self.deque, dtype=np.float32))) if self.deque else 0.0)
     global_avg = property(lambda self: self.total / max(self.count, 1))
-    max = property(lambda self: max(self.deque))
-    value = property(lambda self: self.deque[-1])
+    # empty until the first (one-step-late) metrics arrive: the meter line of iteration 0 then shows zeros
+    max = property(lambda self: max(self.deque) if self.deque else 0.0)
+    value = property(lambda self: self.deque[-1] if self.deque else 0.0)
 
     def __str__(self):
         return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
