@@ -169,7 +169,10 @@ def test_meters_and_checkpoint_roundtrip(native, tmp_path):
     m2 = tiny_model()
     opt2 = ArenaAdamW(m2, lr=1e-3, weight_decay=0.05)
     utils.auto_load_model(args, m2, m2, opt2, utils.NativeScalerWithGradNormCount(), model_ema=None)
-    assert args.start_epoch == 5 and opt2.step_count == 7 and torch.all(opt2.exp_avg == 0.25)
+    assert args.start_epoch == 5 and opt2.step_count == 7
+    # the optimizer entry is per parameter (the reference's torch.optim.AdamW structure): every parameter's slice comes back
+    assert all(torch.all(opt2.exp_avg[o:o + k] == 0.25) for _, o, k, _, _ in m2._layout)
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and set(ck["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
     assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), m.state_dict().values()))
 
 
@@ -306,3 +309,38 @@ def test_epoch_scalars_follow_the_reference_loop_state(native):
     flat = epoch_scalars(opt, 0, 3, None, None, 0, 0.99, 0.9998, -1)
     assert flat == [(f32(1e-3), f32(0.05), f32(0.9998))] * 3
     assert epoch_scalars(opt, 0, 2, None, None, 0, 1.0, 1.0, -1)[0][2] == -1.0       # decay 1: `cur_decay != 1` is false
+
+
+def test_optimizer_state_dict_interchanges_with_torch_adamw(native):
+    """Checkpoint interchange (VERDICT r1 "Missing 8", utils.py:462-479): ArenaAdamW.state_dict() has the structure of the
+    torch.optim.AdamW the reference builds over the same two groups -- torch loads it, and a torch state dict loads into
+    the arenas at the right offsets -- so `checkpoint-N.pth['optimizer']` moves both ways."""
+    from uncertainty_vit_amd.optim_factory import ArenaAdamW, get_parameter_groups
+    m = tiny_model()
+    opt = ArenaAdamW(m, lr=1e-3, weight_decay=0.05)
+    groups, _ = get_parameter_groups(m, 0.05, m.no_weight_decay())
+    ref = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    g = torch.Generator().manual_seed(0)
+    for p in m.parameters():
+        p.grad = torch.randn(p.shape, generator=g)
+    before = m._arena.clone()
+    ref.step(); ref.step()
+    m._arena.copy_(before)                    # torch stepped the shared parameters: restore, only the state matters here
+    tsd = ref.state_dict()
+    opt.load_state_dict(tsd)                  # torch -> arena
+    assert opt.step_count == 2
+    lay = {n: (o, k, shape) for n, o, k, shape, _ in m._layout}
+    order = [n for grp in ("decay", "no_decay") for n in opt.group_names[grp]]
+    for i, n in enumerate(order):
+        off, numel, shape = lay[n]
+        assert torch.equal(opt.exp_avg[off:off + numel].view(shape), tsd["state"][i]["exp_avg"]), n
+        assert torch.equal(opt.exp_avg_sq[off:off + numel].view(shape), tsd["state"][i]["exp_avg_sq"]), n
+    asd = opt.state_dict()                    # arena -> torch
+    assert [g_["params"] for g_ in asd["param_groups"]] == [g_["params"] for g_ in tsd["param_groups"]]
+    ref2 = torch.optim.AdamW(get_parameter_groups(m, 0.05, m.no_weight_decay())[0], lr=1e-3)
+    ref2.load_state_dict(asd)
+    for i in tsd["state"]:
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(ref2.state_dict()["state"][i][k], tsd["state"][i][k])
+        assert float(ref2.state_dict()["state"][i]["step"]) == 2.0
+    assert ArenaAdamW(tiny_model(), 1e-3, 0.05).state_dict()["state"] == {}      # nothing stepped yet: empty, as in torch

@@ -88,6 +88,19 @@ if __name__ == "__main__" and "bench_gemm" in sys.argv[0]:
             row.append(f"{'auto' if v == 3 else 'v%d' % v}: {us:6.1f} us {tf:5.0f} TF")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
     TUNE.nt_variant = 3
+    if "--group" in sys.argv:
+        print("== NT: column tiles per row-tile group of the tile order (nt_group), 256-row kernel ==")
+        TUNE.nt_variant = 1
+        for mode, N, K in ((8, 3072, 768), (2, 3072, 768), (9, 3072, 768), (1, 2304, 768), (0, 3072, 3072)):
+            row = []
+            for gsz in (1, 2, 3, 4, 6, 12):
+                TUNE.nt_group = gsz
+                us, tf = time_nt(mode, M, N, K)
+                row.append(f"g{gsz}: {us:6.1f} us")
+            print(f"{names[mode]:7s} N={N:5d} K={K:5d}: " + " | ".join(row))
+        TUNE.nt_group = 0
+        TUNE.nt_variant = 3
+        sys.exit(0)
     if "--quick" in sys.argv:
         sys.exit(0)
     print("== NT: square references ==")

@@ -233,15 +233,15 @@ void smooth_l1_kernel(const float* __restrict__ out, const float* __restrict__ t
 template <int NV>
 __global__ __launch_bounds__(256)
 void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ mask, bf16* __restrict__ dpatch,
-                      float* __restrict__ dcls, float* __restrict__ dmask, int B, int P, int C) {
+                      float* __restrict__ dcls, float* __restrict__ dmask, int B, int P, int C, int rows_per_block) {
     __shared__ float red[4][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2, N = P + 1;
     float4 ac[NV], am[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) { ac[k] = make_float4(0.f, 0.f, 0.f, 0.f); am[k] = ac[k]; }
     const int M = B * N;
-    const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
-    for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
+    const int row_end = min((int)(blockIdx.x + 1) * rows_per_block, M);
+    for (int row = blockIdx.x * rows_per_block + wave; row < row_end; row += 4) {
         const int b = row / N, t = row - b * N;
         const bool is_cls = t == 0;
         const bool masked = !is_cls && mask[b * P + t - 1] != 0;
@@ -340,7 +340,7 @@ int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, f
                                hipStream_t s) {
     const int g = (int)(sqrtf((float)(N - 1)) + 0.5f);
     const int ntable = (2 * g - 1) * (2 * g - 1) + 3;
-    hipLaunchKernelGGL(relpos_scatter_kernel, dim3(H, 8), dim3(256), ntable * sizeof(float), s, slab, nslab, index, dtable, H, N, NP, ntable);
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3(H, 24), dim3(256), ntable * sizeof(float), s, slab, nslab, index, dtable, H, N, NP, ntable);
     return uvit_check_launch();
 }
 int uvit_ls_bwd_launch(const float* dx, const void* y, const float* gamma, const float* rowscale, void* dy,
@@ -365,8 +365,15 @@ int uvit_smooth_l1_launch(const float* out, const float* target, const int* coun
 int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch, float* dcls, float* dmask_token, int B,
                           int P, int C, hipStream_t s) {
     if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
-    CP_DISPATCH(token_bwd_kernel, C, dim3((B * (P + 1) + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
-                       dcls, dmask_token, B, P, C);
+    // every workgroup ends with 2 x C same-address atomics (d cls_token, d mask_token have ONE accumulator each): with
+    // 32-row workgroups (788 of them at bs = 128) those contended atomics were most of the kernel's 169 us.  One
+    // workgroup per CU-slot instead: <= 512 workgroups.
+    const int M = B * (P + 1);
+    int rpb = (M + 511) / 512;
+    rpb = ((rpb + 3) / 4) * 4;
+    if (rpb < CP_ROWS) rpb = CP_ROWS;
+    CP_DISPATCH(token_bwd_kernel, C, dim3((M + rpb - 1) / rpb), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
+                       dcls, dmask_token, B, P, C, rpb);
     return uvit_check_launch();
 }
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int total_tiles, hipStream_t s) {

@@ -54,22 +54,37 @@ __device__ __forceinline__ ColVals load_cols(const GemmEpi& e, int n, int N) {
     return c;
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7): one v_rcp + one v_exp + 6 FMAs instead of libm erff
-__device__ __forceinline__ void erf_parts(float x, float& erf_v, float& gauss) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    gauss = __expf(-z * z);                                   // exp(-x^2/2)
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.0f - poly * gauss;
-    erf_v = x < 0.f ? -e : e;
+// Exact (erf) GELU for bf16 outputs.  Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz-Stegun 7.1.25,
+//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) exp(-z^2),  t = 1 / (1 + p z),  |error| <= 2.5e-5
+// i.e. |error(Phi)| <= 1.3e-5: two orders below the bf16 half-ulp of the outputs (2e-3 at 1).  The fused GELU epilogues
+// are VALU-bound (a K = 64 launch: 63 us against 42 us for the plain bf16 store of the same bytes), so the formulation
+// minimises instructions: everything is written in |x| (source modifiers are free), constants are folded, and gelu(x)
+// itself needs no sign select:  gelu(x) = max(x, 0) - |x| q,  q = Phi(-|x|) = 0.5 (a1 t + a2 t^2 + a3 t^3) exp(-x^2 / 2).
+//   q      : 1 fma + v_rcp (t), 2 mul + v_exp (gauss), 3 (Horner, 0.5 folded into a_i), 1 mul          = 9 ops
+//   gelu   : + max, fma                                                                                   = 11 ops
+//   gelu'  : + Phi(x) = x < 0 ? q : 1 - q (3 ops), Phi + (x / sqrt(2 pi)) gauss (2 ops)                   = 16 ops for both
+// (round 1: 7.1.26 with 5 Horner terms, an explicit erf sign select and cdf = 0.5 (1 + erf): 16 / 20 ops.)
+__device__ __forceinline__ void gelu_q(float x, float& q, float& gauss) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.33267257f, ax, 1.0f));          // p / sqrt 2 = 0.47047 * 0.70710678
+    const float w = ax * 0.84932180f;                                                      // sqrt(log2(e) / 2): exp(-x^2/2) = exp2(-w^2)
+    gauss = __builtin_amdgcn_exp2f(-w * w);
+    const float poly = t * (0.1740121f + t * (-0.0479399f + t * 0.3739278f));              // 0.5 * {a1, a2, a3}
+    q = poly * gauss;
 }
 __device__ __forceinline__ float gelu_fast(float x) {
-    float e, gs; erf_parts(x, e, gs);
-    return 0.5f * x * (1.0f + e);
+    float q, gs; gelu_q(x, q, gs);
+    return __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+}
+__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gelu, float& grad) {
+    float q, gs; gelu_q(x, q, gs);
+    gelu = __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+    const float cdf = x < 0.f ? q : 1.0f - q;
+    grad = __builtin_fmaf(x * 0.39894228040143268f, gs, cdf);
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
-    float e, gs; erf_parts(x, e, gs);
-    return 0.5f * (1.0f + e) + x * 0.39894228040143268f * gs;
+    float ge, gr; gelu_and_grad_fast(x, ge, gr);
+    return gr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,11 +216,9 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
                 bf16x8 av, dv;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float x = bf2f(v[j]);
-                    float er, gs; erf_parts(x, er, gs);
-                    const float cdf = 0.5f * (1.0f + er);
-                    av[j] = f2bf(x * cdf);
-                    dv[j] = f2bf(cdf + x * 0.39894228040143268f * gs);
+                    float ge, gr; gelu_and_grad_fast(bf2f(v[j]), ge, gr);
+                    av[j] = f2bf(ge);
+                    dv[j] = f2bf(gr);
                 }
                 if (e.out2) *(bf16x8*)((bf16*)e.out2 + o) = dv;
                 *(bf16x8*)((bf16*)e.out + o) = av;
@@ -423,7 +436,8 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = N / T_BN, tiles_m = (M + BM_ - 1) / BM_;
     int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int gw = tiles_n <= 6 ? tiles_n : (tiles_n + ((tiles_n + 5) / 6) - 1) / ((tiles_n + 5) / 6);
+    const int gmax = epi.ngroup > 0 ? epi.ngroup : 6;   // column tiles walked per row tile before moving to the next row tile
+    int gw = tiles_n <= gmax ? tiles_n : (tiles_n + ((tiles_n + gmax - 1) / gmax) - 1) / ((tiles_n + gmax - 1) / gmax);
     int tn0 = 0;
     while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
     const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
@@ -1108,7 +1122,11 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     // ring kernel (2 workgroups per CU): 6 = 128-row tiles, 7 = 160-row tiles
     const bool ring_ok = (N % R_BN) == 0 && M >= 128 && K >= 64 && (K % R_BK) == 0 &&
                          (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;
-    if ((nt_variant == 6 || nt_variant == 7) && ring_ok) {
+    // auto: the residual epilogue (fp32 stream read + write + bf16 branch copy: the heaviest epilogue per flop) on narrow
+    // outputs runs ~5 % faster on the ring kernel, whose two workgroups per CU overlap one's epilogue with the other's K loop
+    // (tools/bench_epilogue.py: N = 768, K = 768: 83.7 vs 88.6 us; K = 3072: 162 vs 170 us)
+    const bool auto_ring = nt_variant == 3 && mode == EPI_RESID && ring_ok && N <= 1024 && M >= 160 * 8;
+    if (((nt_variant == 6 || nt_variant == 7) && ring_ok) || auto_ring) {
         const int rmt = nt_variant == 6 ? 8 : 10;
         const int rgrid = ((M + 16 * rmt - 1) / (16 * rmt)) * (N / R_BN);
         const bf16* a_ = (const bf16*)A; const bf16* w_ = (const bf16*)W;
@@ -1150,6 +1168,9 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
             if (rows_a > 0 && rows_a < M) { m_tail = M - rows_a; M = rows_a; }
         }
     }
+    GemmEpi epi_g = *epi;
+    epi_g.ngroup = tu.nt_group;
+    epi = &epi_g;
     const int bm = mt == 5 ? 320 : T_BM;
     const int grid = variant == 1 ? ((M + bm - 1) / bm) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;

@@ -22,6 +22,7 @@ struct GemmEpi {
     int tokens = 1;                  // RESID: rows per sample
     int patches = 1;                 // PATCH: rows per sample in the GEMM
     int row0 = 0;                    // RESID: sample index of GEMM row m is (m + row0) / tokens (row-split launches)
+    int ngroup = 0;                  // 256x256 kernel: column tiles per row-tile group of the XCD-aware tile order (0 = 6)
 };
 
 // gemm.hip
@@ -32,6 +33,7 @@ struct GemmTune {
     int tn_variant = 3;      // 0: 128x128 kernel, 1: 256x256 staggered kernel, 3: auto
     int tn_target = 512;     // workgroups the wgrad split-K aims for (MI355X sweep: 512 beats 256..1536 on all four wgrad shapes)
     int group_chunks = 0;    // grouped wgrad: 0 = cost model, > 0 = forced token-chunk count
+    int nt_group = 0;        // 256x256 NT kernel: column tiles per row-tile group of the tile order (0 = default 6)
 };
 // tune == nullptr: defaults.  tail_rows_out (nullable) receives the rows that went to the row-split tail launch.
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,

@@ -61,18 +61,67 @@ class ArenaAdamW:
     def zero_grad(self, set_to_none=True):
         pass   # the native step overwrites / re-zeros the gradient arena itself
 
+    # ---- checkpoint interchange with the reference (utils.py:462-479 saves optimizer.state_dict() of a torch.optim.AdamW
+    # built over these two groups): same structure both ways --
+    #   'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, indices running over group 0 (decay) then group 1
+    #   (no_decay) in named_parameters() order; 'param_groups': hyper-parameters + 'params': [indices].
+    # Parameters that never receive a gradient (the two-stream model's dead attn.cov_qkv.weight) have no 'state' entry,
+    # exactly as in torch (state is created on the first step with a gradient).
+    def _index(self):
+        lay = {n: (o, k, shape, d) for n, o, k, shape, d in self.model._layout}
+        order = [n for grp in ("decay", "no_decay") for n in self.group_names[grp]]
+        return lay, order
+
     def state_dict(self):
         self._ensure_state()
-        return {"state": {"step": self.step_count, "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        lay, order = self._index()
+        state, i0 = {}, 0
+        groups = []
+        for g, grp in zip(self.param_groups, ("decay", "no_decay")):
+            names = self.group_names[grp]
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "amsgrad": False, "maximize": False, "foreach": None,
+                           "capturable": False, "differentiable": False, "fused": None,
+                           "params": list(range(i0, i0 + len(names)))})
+            i0 += len(names)
+        if self.step_count > 0:
+            for i, n in enumerate(order):
+                off, numel, shape, frozen = lay[n]
+                if frozen == 2:
+                    continue
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + numel].view(shape).cpu().clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + numel].view(shape).cpu().clone()}
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
         self._ensure_state()
-        self.step_count = int(sd["state"]["step"])
-        self.exp_avg.copy_(sd["state"]["exp_avg"])
-        self.exp_avg_sq.copy_(sd["state"]["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        st = sd["state"]
+        if "exp_avg" in st:                    # round-1 files of this code base: flat arenas
+            self.step_count = int(st["step"])
+            self.exp_avg.copy_(st["exp_avg"])
+            self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        else:                                  # torch.optim.AdamW layout (the reference's checkpoints)
+            lay, order = self._index()
+            n_expected = sum(len(g["params"]) for g in sd["param_groups"])
+            if n_expected != len(order):
+                raise ValueError(f"optimizer state has {n_expected} parameters, the model has {len(order)}")
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            steps = set()
+            for i, n in enumerate(order):
+                e = st.get(i, st.get(str(i)))
+                if e is None:
+                    continue
+                off, numel, shape, _ = lay[n]
+                self.exp_avg[off:off + numel].view(shape).copy_(e["exp_avg"])
+                self.exp_avg_sq[off:off + numel].view(shape).copy_(e["exp_avg_sq"])
+                steps.add(int(float(e["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused step keeps one count")
+            self.step_count = steps.pop() if steps else 0
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s_.items() if k in ("lr", "betas", "eps", "weight_decay", "lr_scale")})
+            g["betas"] = tuple(g["betas"])
 
 
 def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
