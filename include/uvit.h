@@ -91,6 +91,9 @@ typedef struct uvit_step_params {
      * depend on the iteration (a captured step can be replayed). */
     const float* sched_dev;
     int32_t sched_len, sched_index;
+    /* flag-gated arithmetic of the step (no BASELINE config switches it on): */
+    int32_t layer_results_fc;         /* --layer_results fc: targets from the teacher's MLP-branch outputs (modeling_cyclical.py:199-205) */
+    float var_w0, var_margin0;        /* variance term, engine_for_cyclical.py:130-139,161 (var_w0 <= 0: off) */
 } uvit_step_params;
 
 int uvit_version(void);
@@ -167,8 +170,8 @@ int uvit_engine_set_streams(uvit_engine* e, int dual);
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */
 int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
 int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
-/* enqueues the copy of {loss, grad_norm} of the last step into (pinned) host memory behind the step's kernels and returns:
- * the caller reads the two floats after an event it records on `stream` has completed (engine_for_cyclical.py:164,186
+/* enqueues the copy of 8 floats {loss, grad_norm, -, -, std_loss0 (the `loss_var0` meter), ...} of the last step into (pinned) host memory behind the step's kernels and returns:
+ * the caller reads them after an event it records on `stream` has completed (engine_for_cyclical.py:164,186
  * sync twice per step instead).  A step whose loss or gradient norm is not finite leaves the weights untouched, and so
  * does every later step of that engine. */
 int uvit_engine_read_stats_async(uvit_engine* e, float* host_out2, uvit_stream stream);
@@ -250,6 +253,11 @@ int uvit_op_wasserstein_loss(const float* out_m, const float* out_c, const float
 /* target builder, engine_for_cyclical.py:92-122 */
 int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
                          int C, float eps, uvit_stream stream);
+/* variance term of the loss (engine_for_cyclical.py:130-139): z0_c = sqrt(var_r(out[r, c]) + 1e-6) over the *count_dev valid rows
+ * (unbiased), std_loss0 = sum_c relu(margin - z0_c) / C.  *loss += w * loss_scale * std_loss0, *std_loss0_out = std_loss0, and
+ * the gradient is ADDED to dout_bf16 (which already holds the regression gradient).  scratch: 2 * C + 16 floats. */
+int uvit_op_variance_loss(const float* out, const int32_t* count_dev, float w, float margin, float loss_scale, float* scratch,
+                          float* loss, float* std_loss0_out, void* dout_bf16, int Mmax, int C, uvit_stream stream);
 int uvit_op_target_finalize(float* acc, const int32_t* count, int n_layers, int post_ln, int Mmax, int C, float eps,
                             uvit_stream stream);
 int uvit_op_mask_compact(const int64_t* mask, int32_t* rowidx, int32_t* count, int B, int P, uvit_stream stream);

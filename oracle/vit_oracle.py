@@ -91,6 +91,8 @@ class StepHParams:
     betas: Sequence[float] = (0.9, 0.999)
     eps: float = 1e-8
     ema_decay: float = 0.9998
+    var_w0: float = 0.0          # weight of the variance term (engine_for_cyclical.py:130-139, 161)
+    var_margin0: float = 0.5
 
 
 # --------------------------------------------------------------------------------------
@@ -332,14 +334,25 @@ def build_targets(layer_outs: List[Tensor], mask: Tensor, hp: StepHParams) -> Te
     return t.reshape(-1, C)[mask.flatten().bool()]
 
 
+def variance_term(outputs: Tensor, hp: StepHParams) -> Tensor:
+    """engine_for_cyclical.py:130-139: z0 = sqrt(var over the masked rows (unbiased) + 1e-6) per channel;
+    std_loss0 = sum(relu(var_margin0 - z0)) / channels when var_w0 > 0, else 0."""
+    z0 = torch.sqrt(outputs.float().reshape(-1, outputs.shape[-1]).var(dim=0) + 1e-6)
+    if hp.var_w0 > 0:
+        return torch.sum(F.relu(hp.var_margin0 - z0)) / z0.shape[0]
+    return torch.zeros((), dtype=torch.float32)
+
+
 def regression_loss(outputs: Tensor, targets: Tensor, hp: StepHParams) -> Tensor:
-    """engine_for_cyclical.py:130-163 with var_w0 == 0 (std_loss0 contributes 0)."""
+    """engine_for_cyclical.py:130-163: smooth-L1 / MSE + var_w0 * std_loss0, then loss_scale."""
     outputs = outputs.float()
     assert outputs.shape == targets.shape
     if hp.l2_loss:
         loss = F.mse_loss(outputs, targets)
     else:
         loss = F.smooth_l1_loss(outputs, targets, beta=hp.l1_beta)
+    if hp.var_w0 > 0:
+        loss = loss + variance_term(outputs, hp) * hp.var_w0
     if hp.loss_scale != -1:
         loss = loss * hp.loss_scale
     return loss
@@ -395,6 +408,7 @@ class StepResult:
     outputs: Tensor
     targets: Tensor
     grads: Dict[str, Tensor]
+    loss_var0: float = 0.0
 
 
 def train_step(params: Dict[str, Tensor], ema: Dict[str, Tensor], m: Dict[str, Tensor],
@@ -420,7 +434,9 @@ def train_step(params: Dict[str, Tensor], ema: Dict[str, Tensor], m: Dict[str, T
     with torch.no_grad():
         adamw_step(params, grads, m, v, step, hp, lr, wd)
         ema_update(ema, params, hp.ema_decay if decay is None else decay)
-    return StepResult(float(loss.detach()), float(gnorm), outputs.detach(), targets, raw)
+    res = StepResult(float(loss.detach()), float(gnorm), outputs.detach(), targets, raw)
+    res.loss_var0 = float(variance_term(outputs.detach(), hp))     # the `loss_var0` meter (engine_for_cyclical.py:198)
+    return res
 
 
 # --------------------------------------------------------------------------------------

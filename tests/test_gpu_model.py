@@ -247,3 +247,27 @@ def test_loss_curve_vitb_100_steps(golden_dir):
     assert err.max() < 1e-3, (err.max(), int(err.argmax()))
     gn = np.array([s["grad_norm"] for s in st])
     assert np.all(np.abs(gn - fx["grad_norm"]) <= 5e-2 * fx["grad_norm"] + 1e-3), np.abs(gn - fx["grad_norm"]).max()
+
+
+def test_flag_gated_fc_targets_and_variance_term(golden_dir):
+    """`--layer_results fc` targets and the variance term (`--var_w0 1 --var_margin0 1`; engine_for_cyclical.py:88-139): two
+    steps of the HIP path against the reference's own numbers (tests/golden/model_flags.npz) and, per tensor, the oracle."""
+    fx = np.load(os.path.join(golden_dir, "model_flags.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    model, sd0 = native_model(cfg)
+    ema, opt = native_trainer(model)
+    batches = [(closed_form_images(f"flags/{s}", B, img), torch.from_numpy(fx[f"mask{s}"])) for s in range(steps)]
+    kw = dict(layer_results="fc", var_w0=1.0, var_margin0=1.0)
+    st = native_steps(model, ema, opt, [(batches[0][0].cuda(), batches[0][1].cuda())], [1, 2], **kw)
+    assert st[0]["loss"] == pytest.approx(float(fx["loss"][0]), rel=5e-3)
+    assert st[0]["loss_var0"] == pytest.approx(float(fx["loss_var0"][0]), rel=5e-3) and st[0]["loss_var0"] > 0.5
+    assert st[0]["grad_norm"] == pytest.approx(float(fx["grad_norm"][0]), rel=3e-2)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    p, e, m1, v1 = oracle_state(sd0)
+    hp = vo.StepHParams(target_layers=(1, 2), layer_results="fc", var_w0=1.0, var_margin0=1.0)
+    ref = vo.train_step(p, e, m1, v1, cfg, hp, batches[0][0], batches[0][1], 1)
+    assert_grads_close(grads, ref.grads, what="[flags] ")
+    st += native_steps(model, ema, opt, [(batches[1][0].cuda(), batches[1][1].cuda())], [1, 2], start=1, **kw)
+    assert st[1]["loss"] == pytest.approx(float(fx["loss"][1]), rel=2e-2)
+    assert st[1]["loss_var0"] == pytest.approx(float(fx["loss_var0"][1]), rel=2e-2)

@@ -213,3 +213,27 @@ def test_loss_curve_vitb_first_steps(golden_dir):
     losses = [vo.train_step(p, ema, m, v, cfg, hp, *fixed[s % 4], s + 1).loss for s in range(12)]
     np.testing.assert_allclose(np.array(losses), fx["loss"][:12], atol=2e-4, rtol=0)
     assert fx["loss"][0] - fx["loss"][-1] > 0.1          # the curve really moves: 0.40 -> 0.24
+
+
+def test_flag_gated_targets_and_variance_term(golden_dir):
+    """`--layer_results fc` targets + the variance term `--var_w0 1 --var_margin0 1` (engine_for_cyclical.py:88-139),
+    which no BASELINE config switches on: the oracle against the reference's own two steps."""
+    fx = np.load(os.path.join(golden_dir, "model_flags.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    p = closed_form_state(vo.param_shapes(cfg), gamma=0.1)
+    hp = vo.StepHParams(target_layers=(1, 2), layer_results="fc", var_w0=1.0, var_margin0=1.0)
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    for s in range(steps):
+        x = closed_form_images(f"flags/{s}", B, img)
+        res = vo.train_step(p, ema, m, v, cfg, hp, x, torch.from_numpy(fx[f"mask{s}"]), s + 1)
+        assert res.loss == pytest.approx(float(fx["loss"][s]), rel=2e-4)
+        assert res.loss_var0 == pytest.approx(float(fx["loss_var0"][s]), rel=2e-4) and res.loss_var0 > 0.5
+        assert res.grad_norm == pytest.approx(float(fx["grad_norm"][s]), rel=2e-3)
+        if s == 0:
+            for n in entries(fx, "grad0"):
+                check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
+    for n in entries(fx, "post"):
+        check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)

@@ -47,7 +47,7 @@ def build(mc, img, dim, depth, heads, init_values):
 
 
 def run_reference_steps(eng, model, batches, target_layers, lr=2e-3, wd=0.05, clip=3.0,
-                        l1_beta=2.0, decay=0.9998):
+                        l1_beta=2.0, decay=0.9998, layer_results="end", var_w0=0.0, var_margin0=0.5):
     import optim_factory
     import timm.utils as U
     ema = U.ModelEmaV2(model, decay=decay)
@@ -65,12 +65,13 @@ def run_reference_steps(eng, model, batches, target_layers, lr=2e-3, wd=0.05, cl
         stats = eng.train_one_epoch(
             model, ema, 0, decay, decay, target_layers, loader, opt, torch.device("cpu"), 0, scaler,
             max_norm=clip, l1_beta=l1_beta, log_writer=None, lr_scheduler=None, start_steps=s,
-            lr_schedule_values=None, wd_schedule_values=None, l2_loss=False, layer_results="end",
-            var_w0=0.0, var_w1=0.0, start_lr_decay_at_step=-1, loss_scale=-1, mask_dropout_prob=-1.0,
+            lr_schedule_values=None, wd_schedule_values=None, l2_loss=False, layer_results=layer_results,
+            var_w0=var_w0, var_w1=0.0, var_margin0=var_margin0, start_lr_decay_at_step=-1, loss_scale=-1, mask_dropout_prob=-1.0,
             target_layer_norm_last=True, target_batch_norm=False, target_instance_norm=False,
             post_target_instance_norm=False, post_target_layer_norm=True, stochastic=False)
         rec["loss"].append(stats["loss"])
         rec["grad_norm"].append(float(stats["grad_norm"]))
+        rec.setdefault("loss_var0", []).append(float(stats["loss_var0"]))
         if s == 0:
             pn = [n for n, _ in model.named_parameters()]
             first_grads = {n: g for n, g in zip(pn, scaler.grads) if g is not None}
@@ -116,6 +117,28 @@ def gen_model_case(mc, eng, tag, img, dim, depth, heads, init_values, B, n_mask,
     out["groups/no_decay"] = np.array(groups["no_decay"])
     np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
     print("wrote", tag, "loss", rec["loss"], "gnorm", rec["grad_norm"])
+
+
+def gen_flag_case(mc, eng):
+    """The flag-gated arithmetic of the step that no BASELINE config switches on (VERDICT r1 "Missing 7"), from the reference:
+    `--layer_results fc` targets (teacher MLP-branch outputs, modeling_cyclical.py:199-205) and the variance term
+    `--var_w0 1 --var_margin0 1` (engine_for_cyclical.py:130-139); tiny model, 2 steps."""
+    img, dim, depth, heads, B, n_mask = 48, 128, 3, 2, 5, 4
+    model = build(mc, img, dim, depth, heads, 0.1)
+    batches = [(closed_form_images(f"flags/{s}", B, img), exact_masks(B, 9, n_mask, 700 + s)) for s in range(2)]
+    model.train()
+    rec, grads, ema, _ = run_reference_steps(eng, model, batches, [1, 2], layer_results="fc", var_w0=1.0, var_margin0=1.0)
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, 2], dtype=np.int64), "loss": np.array(rec["loss"]),
+           "grad_norm": np.array(rec["grad_norm"]), "loss_var0": np.array(rec["loss_var0"])}
+    for s, (_, bm) in enumerate(batches):
+        out[f"mask{s}"] = bm.numpy()
+    for k, v in grads.items():
+        put(out, "grad0/" + k, v)
+    for k, v in model.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "post/" + k, v)
+    np.savez_compressed(os.path.join(OUT, "model_flags.npz"), **out)
+    print("wrote flag case: loss", rec["loss"], "loss_var0", rec["loss_var0"], "gnorm", rec["grad_norm"])
 
 
 CURVE_LR = 1e-4   # constant; the README recipe warms up from 1e-6, 2e-3 from step 0 is chaotic on a tiny model
@@ -351,6 +374,8 @@ def main():
         gen_loss_curve(mc, eng)
     if a.only in (None, "vitb"):
         gen_vitb_spot(mc)
+    if a.only in (None, "flags"):
+        gen_flag_case(mc, eng)
     if a.only in (None, "dvitb"):
         gen_dist_vitb_spot(mc, eng)
     if a.only in (None, "curveB"):

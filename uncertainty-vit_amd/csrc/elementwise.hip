@@ -529,3 +529,77 @@ int uvit_synth_batch_launch(float* images, int64_t* mask, int B, int chans, int 
     if (mask) hipLaunchKernelGGL(synth_mask_kernel, dim3(B), dim3(256), patches * sizeof(uint32_t), s, mask, patches, n_mask, key ^ 0xA5A5A5A5u);
     return uvit_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// Variance term of the loss (engine_for_cyclical.py:130-139, 161; off in every BASELINE config):
+//   z0_c = sqrt(var_r(out[r, c]) + 1e-6)  (unbiased, over the masked rows);  std_loss0 = sum_c relu(margin - z0_c) / C
+//   d std_loss0 / d out[r, c] = -(out[r, c] - mean_c) / (C (M - 1) z0_c)   where z0_c < margin, else 0
+// Two passes for the column statistics (mean, then centred squares: no cancellation), one for loss + gradient.
+// scratch: [0, C) column sums -> means, [C, 2C) centred square sums, [2C] std_loss0.
+// ------------------------------------------------------------------------------------------
+#define VL_ROWS 64
+template <int PASS>
+__global__ __launch_bounds__(256)
+void varloss_colstat_kernel(const float* __restrict__ out, const int* __restrict__ count, float* __restrict__ scratch, int Mmax, int C) {
+    const int n = min(*count, Mmax);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * VL_ROWS, r1 = min(r0 + VL_ROWS, n);
+    const float mean = PASS == 1 ? scratch[c] / (float)max(n, 1) : 0.f;
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float v = out[(size_t)r * C + c];
+        acc += PASS == 0 ? v : (v - mean) * (v - mean);
+    }
+    if (r0 < r1) atomicAdd(scratch + PASS * C + c, acc);
+}
+
+__global__ __launch_bounds__(256)
+void varloss_sum_kernel(const int* __restrict__ count, float* __restrict__ scratch, float w, float margin, float* __restrict__ loss,
+                        float* __restrict__ std_out, int Mmax, int C) {
+    __shared__ float red[4];
+    const int n = min(*count, Mmax);
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float z0 = sqrtf(scratch[C + c] / (float)max(n - 1, 1) + 1e-6f);
+        acc += fmaxf(margin - z0, 0.f);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+        scratch[2 * C] = s;
+        if (std_out) *std_out = s;
+        atomicAdd(loss, w * s);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void varloss_grad_kernel(const float* __restrict__ out, const int* __restrict__ count, const float* __restrict__ scratch, float w,
+                         float margin, bf16* __restrict__ dout, int Mmax, int C) {
+    const int n = min(*count, Mmax);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C || n < 2) return;
+    const float mean = scratch[c] / (float)n;
+    const float z0 = sqrtf(scratch[C + c] / (float)(n - 1) + 1e-6f);
+    if (!(z0 < margin)) return;
+    const float k = -w / ((float)C * (float)(n - 1) * z0);
+    const int r0 = blockIdx.y * VL_ROWS, r1 = min(r0 + VL_ROWS, n);
+    for (int r = r0; r < r1; ++r) {
+        const size_t o = (size_t)r * C + c;
+        dout[o] = f2bf(bf2f(dout[o]) + k * (out[o] - mean));
+    }
+}
+
+int uvit_variance_loss_launch(const float* out, const int* count, float w, float margin, float loss_scale, float* scratch, float* loss,
+                              float* std_loss0_out, void* dout, int Mmax, int C, hipStream_t s) {
+    if (Mmax < 1 || C < 1) return UVIT_ERR_SHAPE;
+    if (hipMemsetAsync(scratch, 0, (2 * (size_t)C + 16) * sizeof(float), s) != hipSuccess) return UVIT_ERR_LAUNCH;
+    const dim3 grid((C + 255) / 256, (Mmax + VL_ROWS - 1) / VL_ROWS);
+    hipLaunchKernelGGL(varloss_colstat_kernel<0>, grid, dim3(256), 0, s, out, count, scratch, Mmax, C);
+    hipLaunchKernelGGL(varloss_colstat_kernel<1>, grid, dim3(256), 0, s, out, count, scratch, Mmax, C);
+    hipLaunchKernelGGL(varloss_sum_kernel, dim3(1), dim3(256), 0, s, count, scratch, w * loss_scale, margin, loss, std_loss0_out, Mmax, C);
+    hipLaunchKernelGGL(varloss_grad_kernel, grid, dim3(256), 0, s, out, count, scratch, w * loss_scale, margin, (bf16*)dout, Mmax, C);
+    return uvit_check_launch();
+}

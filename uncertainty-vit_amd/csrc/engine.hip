@@ -152,6 +152,7 @@ struct uvit_engine {
     float *dp_scales, *dp_rates;
     float *loss, *gnorm; double* sumsq;
     float* wl_scratch;     // Wasserstein loss: scalars + per-row distances
+    float* var_scratch;    // variance term: column sums / centred squares (2 C + 16 floats)
     int* poisoned;         // sticky: set by the first step whose loss / gradient norm is not finite; AdamW and EMA then skip every step
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
@@ -222,6 +223,7 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->wl_scratch = b.take<float>(16 + BPp);
     e->poisoned = b.take<int>(64);
+    e->var_scratch = b.take<float>(2 * C + 16);
     e->tdesc = b.take<TransposeDesc>(7 * c.depth + 4);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
     e->grep = b.take<float>((size_t)NREP * e->n_nd);
@@ -517,9 +519,10 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
             for (int k = 0; k < hp_targets->n_target_layers; ++k) {
                 if (hp_targets->target_layers[k] != l) continue;
                 if (!hp_targets->target_layer_norm_last) return UVIT_ERR_ARG;
-                for (int st = 0; st < e->S; ++st)
+                for (int st = 0; st < e->S; ++st)       // --layer_results fc: the block's MLP-branch output x_out - x_mid
                     CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
-                                                   Bc * e->P, e->C, 1e-5f, s));
+                                                   Bc * e->P, e->C, 1e-5f, s,
+                                                   hp_targets->layer_results_fc ? e->tXM + (size_t)st * e->Mpad * e->C : nullptr));
                 ++n_t;
             }
         }
@@ -627,6 +630,9 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163 (+ WassersteinLoss for the two-stream model, :152-161)
     const float ls = hp->loss_scale == -1.0f ? 1.0f : hp->loss_scale;
     CHECK(uvit_smooth_l1_launch(e->outputs[0], e->targets[0], e->count, hp->l1_beta, hp->l2_loss, ls, e->loss, e->dout[0], BP, C, s));
+    if (hp->var_w0 > 0.f)      // variance term on the mean-stream outputs (engine_for_cyclical.py:130-139); std_loss0 -> loss[4]
+        CHECK(uvit_variance_loss_launch(e->outputs[0], e->count, hp->var_w0, hp->var_margin0, ls, e->var_scratch, e->loss, e->loss + 4,
+                                        e->dout[0], BP, C, s));
     if (e->S == 2)
         CHECK(uvit_wasserstein_loss_launch(e->outputs[0], e->outputs[1], e->targets[0], e->targets[1], e->count, hp->lambda_pretraining,
                                            ls, e->wl_scratch, e->loss, e->dout[0], e->dout[1], BP, C, s));
@@ -830,7 +836,7 @@ extern "C" int uvit_train_step(uvit_engine* e, const float* images, const int64_
 
 extern "C" int uvit_engine_read_stats_async(uvit_engine* e, float* host_out2, uvit_stream stream) {
     if (!e || !host_out2) return UVIT_ERR_ARG;
-    HIPCHECK(hipMemcpyAsync(host_out2, e->loss, 2 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHECK(hipMemcpyAsync(host_out2, e->loss, 8 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return UVIT_OK;
 }
 
@@ -940,6 +946,11 @@ extern "C" int uvit_op_wasserstein_loss(const float* om, const float* oc, const 
                                         float ls, float* scratch, float* loss, void* dm, void* dc, int Mmax, int C, uvit_stream st) {
     if (!om || !oc || !tm || !tc || !count || !scratch || !loss || !dm || !dc || Mmax < 1 || C < 1) return UVIT_ERR_ARG;
     return uvit_wasserstein_loss_launch(om, oc, tm, tc, count, lam, ls, scratch, loss, dm, dc, Mmax, C, S(st));
+}
+extern "C" int uvit_op_variance_loss(const float* out, const int32_t* count, float w, float margin, float ls, float* scratch, float* loss,
+                                     float* std_out, void* dout, int Mmax, int C, uvit_stream st) {
+    if (!out || !count || !scratch || !loss || !dout) return UVIT_ERR_ARG;
+    return uvit_variance_loss_launch(out, count, w, margin, ls, scratch, loss, std_out, dout, Mmax, C, S(st));
 }
 extern "C" int uvit_op_target_accum(const float* x, const int32_t* rowidx, const int32_t* count, float* acc, int first, int Mmax,
                                     int C, float eps, uvit_stream st) {

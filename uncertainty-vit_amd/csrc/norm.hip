@@ -223,11 +223,12 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
     }
 }
 
-// acc[i] (+)= layer_norm(x[rowidx[i]])  (no affine)
+// acc[i] (+)= layer_norm(x[rowidx[i]] - sub[rowidx[i]])  (no affine; sub == nullptr: 0).  `sub` = the stream before the
+// MLP branch: x - sub is the block's `fc` output, the `--layer_results fc` target (modeling_cyclical.py:199-205).
 template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
-void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, const int* __restrict__ count,
-                         float* __restrict__ acc, int first, int Mmax, int C, float eps) {
+void target_accum_kernel(const float* __restrict__ x, const float* __restrict__ sub, const int* __restrict__ rowidx,
+                         const int* __restrict__ count, float* __restrict__ acc, int first, int Mmax, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= Mmax) return;
@@ -241,6 +242,12 @@ void target_accum_kernel(const float* __restrict__ x, const int* __restrict__ ro
     }
     RowVec<NV> r;
     load_row(r, x + (size_t)rowidx[row] * C, C, lane);
+    if (sub) {
+        RowVec<NV> q;
+        load_row(q, sub + (size_t)rowidx[row] * C, C, lane);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { r.v[k].x -= q.v[k].x; r.v[k].y -= q.v[k].y; r.v[k].z -= q.v[k].z; r.v[k].w -= q.v[k].w; }
+    }
     float mean, rstd;
     row_stats(r, C, lane, eps, mean, rstd);
 #pragma unroll
@@ -346,9 +353,9 @@ int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx
     return uvit_check_launch();
 }
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
-                             int C, float eps, hipStream_t s) {
+                             int C, float eps, hipStream_t s, const float* sub) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
-    LN_DISPATCH(target_accum_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, rowidx,
+    LN_DISPATCH(target_accum_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, sub, rowidx,
                        count, acc, first, Mmax, C, eps);
     return uvit_check_launch();
 }

@@ -92,7 +92,9 @@ int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* r
                                int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
 int uvit_reduce_replicas_launch(const float* rep, float* out, size_t n, int nrep, size_t stride, hipStream_t s);
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
-                             int C, float eps, hipStream_t s);
+                             int C, float eps, hipStream_t s, const float* sub = nullptr);   // sub: rows subtracted before the LayerNorm
+int uvit_variance_loss_launch(const float* out, const int* count, float w, float margin, float loss_scale, float* scratch,
+                              float* loss, float* std_loss0_out, void* dout_bf16, int Mmax, int C, hipStream_t s);
 int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
                                 hipStream_t s);
 

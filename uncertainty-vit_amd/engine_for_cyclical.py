@@ -220,12 +220,16 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     print(' <<<<<<<< layer_results >>>>>>>>', layer_results)
     print(' <<<<<<<< var_w0, var_w1 >>>>>>>>', var_w0, var_w1)
     # flags whose arithmetic is not on the configured hot path are refused, never approximated
-    if layer_results != 'end' or target_batch_norm or target_instance_norm or post_target_instance_norm or var_w0 > 0 \
+    if layer_results not in ('end', 'fc') or target_batch_norm or target_instance_norm or post_target_instance_norm \
             or not target_layer_norm_last:
-        raise NotImplementedError("only layer_results='end' with target layer-norm (README.md:11-25 recipe) is native")
+        raise NotImplementedError("batch/instance-norm targets and targets without the per-layer layer-norm are not native "
+                                  "(README.md:11-25 recipe: layer-norm targets)")
     model.train()
     net = _unwrap(model)
     teacher = model_ema.module
+    if stochastic and (layer_results != 'end' or var_w0 > 0):
+        raise NotImplementedError("the two-stream step is native for layer_results='end', var_w0=0 (modeling_cyclical_dist.py:136-139 "
+                                  "collects only 'end' results)")
     if bool(stochastic) != bool(getattr(net, "_two_stream", False)):
         # the reference unpacks (mean, cov) pairs when stochastic (engine_for_cyclical.py:70,126): only the two-stream
         # model (dist_beit_base_patch16_224) returns them -- SURVEY.md F8
@@ -239,7 +243,7 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     world = utils.get_world_size()
     reducer = None
     engine = None
-    ring = torch.zeros(4, 2, dtype=torch.float32)
+    ring = torch.zeros(4, 8, dtype=torch.float32)      # per slot: loss, grad_norm, -, -, std_loss0 (loss_var0 meter), ...
     events = None
     if torch.cuda.is_available():
         ring = ring.pin_memory()
@@ -265,7 +269,7 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
         metric_logger.update(loss_scale=entry["loss_scale"])
         metric_logger.update(lr=entry["lr"])
         metric_logger.update(min_lr=entry["min_lr"])
-        metric_logger.update(loss_var0=0)
+        metric_logger.update(loss_var0=float(ring[slot, 4]) if var_w0 > 0 else 0)       # std_loss0 (engine_for_cyclical.py:198)
         metric_logger.update(weight_decay=entry["weight_decay"])
         metric_logger.update(grad_norm=grad_norm)
         metric_logger.update(cur_decay=entry["cur_decay"])
@@ -324,6 +328,8 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
             if sched_dev is None:
                 sched_dev = torch.tensor([[sc[k] for sc in scalars] for k in range(3)], dtype=torch.float32, device=samples.device)
             hp.sched_dev, hp.sched_len, hp.sched_index = sched_dev.data_ptr(), len(scalars), step
+        hp.layer_results_fc = int(layer_results == 'fc')
+        hp.var_w0, hp.var_margin0 = float(var_w0), float(var_margin0)
         native_step(engine, reducer, samples, mask, hp)
         optimizer.step_count += 1
 

@@ -51,7 +51,8 @@ class StepParams(C.Structure):
                 ("weight_decay", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("opt_step", C.c_int32), ("ema_decay", C.c_float), ("do_ema", C.c_int32), ("grad_scale", C.c_float),
                 ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float),
-                ("sched_dev", C.c_void_p), ("sched_len", C.c_int32), ("sched_index", C.c_int32)]
+                ("sched_dev", C.c_void_p), ("sched_len", C.c_int32), ("sched_index", C.c_int32),
+                ("layer_results_fc", C.c_int32), ("var_w0", C.c_float), ("var_margin0", C.c_float)]
 
 
 class WgradProblem(C.Structure):
@@ -127,6 +128,7 @@ _PROTOTYPES = {
     "uvit_op_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp]),
     "uvit_op_smooth_l1": (_i, [_vp, _vp, _vp, _f, _i, _f, _vp, _vp, _i, _i, _vp]),
     "uvit_op_target_accum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "uvit_op_variance_loss": (_i, [_vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "uvit_op_target_finalize": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "uvit_op_mask_compact": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "uvit_op_im2col": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
