@@ -30,7 +30,7 @@ typedef void* uvit_stream;   /* hipStream_t */
 typedef struct uvit_config {
     int32_t img_size, patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden;
     int32_t use_shared_rel_pos_bias;  /* modeling_cyclical.py:84-89 */
-    int32_t use_abs_pos_emb;          /* must be 0 (run_cyclical.py:55 default) */
+    int32_t use_abs_pos_emb;          /* --abs_pos_emb (run_cyclical.py:55, default off): pos_embed (1, N, C) added after the cls concat */
     int32_t batch;
     float ln_eps;                     /* 1e-6, modeling_cyclical.py:294 */
     float attn_drop_rate;             /* --attn_drop_rate */

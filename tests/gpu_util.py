@@ -17,7 +17,7 @@ def native_model(cfg: vo.VitConfig, gamma=None, device="cuda", two_stream=False)
     m = cls(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
             num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
             norm_layer=partial(torch.nn.LayerNorm, eps=cfg.ln_eps), init_values=cfg.init_values,
-            use_shared_rel_pos_bias=cfg.use_shared_rel_pos_bias, use_abs_pos_emb=False,
+            use_shared_rel_pos_bias=cfg.use_shared_rel_pos_bias, use_abs_pos_emb=cfg.use_abs_pos_emb and not two_stream,
             drop_path_rate=cfg.drop_path_rate, attn_drop_rate=cfg.attn_drop_rate)
     shapes = vd.param_shapes(cfg) if two_stream else vo.param_shapes(cfg)
     sd = closed_form_state(shapes, gamma=cfg.init_values if gamma is None else gamma)

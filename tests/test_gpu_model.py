@@ -271,3 +271,31 @@ def test_flag_gated_fc_targets_and_variance_term(golden_dir):
     st += native_steps(model, ema, opt, [(batches[1][0].cuda(), batches[1][1].cuda())], [1, 2], start=1, **kw)
     assert st[1]["loss"] == pytest.approx(float(fx["loss"][1]), rel=2e-2)
     assert st[1]["loss_var0"] == pytest.approx(float(fx["loss_var0"][1]), rel=2e-2)
+
+
+def test_abs_pos_emb_forward_and_steps(golden_dir):
+    """`--abs_pos_emb` (pos_embed added after the cls concat, gradient = batch sum, no-decay group): forward and two steps
+    against the reference's numbers (tests/golden/model_abspos.npz) and the oracle's gradients."""
+    fx = np.load(os.path.join(golden_dir, "model_abspos.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1, use_abs_pos_emb=True)
+    model, sd0 = native_model(cfg)
+    assert [n for n in model.state_dict() if not n.endswith("relative_position_index")] == \
+        [n for n in fx["names"].tolist() if not n.endswith("relative_position_index")]
+    model.eval()
+    x0, m0 = closed_form_images("abspos/0", B, img), torch.from_numpy(fx["mask0"])
+    ends = model(x0.cuda(), None, True, layer_results="end")
+    for i in range(depth):
+        check_entry(fx, f"fwd/end{i}", ends[i], ACT_RT, ACT_AT)
+    check_entry(fx, "fwd/student_masked", model(x0.cuda(), m0.cuda(), return_all_tokens=False), ACT_RT, ACT_AT)
+    ema, opt = native_trainer(model)
+    assert "pos_embed" in opt.group_names["no_decay"]
+    st = native_steps(model, ema, opt, [(x0.cuda(), m0.cuda())], [1])
+    assert st[0]["loss"] == pytest.approx(float(fx["loss"][0]), rel=5e-3)
+    assert st[0]["grad_norm"] == pytest.approx(float(fx["grad_norm"][0]), rel=3e-2)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    p, e, m1, v1 = oracle_state(sd0)
+    ref = vo.train_step(p, e, m1, v1, cfg, vo.StepHParams(target_layers=(1,)), x0, m0, 1)
+    assert_grads_close(grads, ref.grads, what="[abs-pos] ")
+    st += native_steps(model, ema, opt, [(closed_form_images("abspos/1", B, img).cuda(), torch.from_numpy(fx["mask1"]).cuda())], [1], start=1)
+    assert st[1]["loss"] == pytest.approx(float(fx["loss"][1]), rel=2e-2)

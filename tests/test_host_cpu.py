@@ -108,9 +108,15 @@ def test_no_cpu_fallback_and_rejected_options(native):
     m = tiny_model()
     with pytest.raises(native.UvitError):
         m(torch.zeros(1, 3, 48, 48), None, True, layer_results="end")
-    for kw in (dict(gp_layer=True), dict(use_abs_pos_emb=True), dict(init_values=None), dict(embed_dim=96, num_heads=2)):
+    for kw in (dict(gp_layer=True), dict(sinkformer=True), dict(init_values=None), dict(embed_dim=96, num_heads=2)):
         with pytest.raises((NotImplementedError, TypeError)):
             tiny_model(**kw)
+    # --abs_pos_emb is native since round 2: pos_embed (1, N, C) sits right after the tokens in the state dict
+    # (modeling_cyclical.py:80-84) and in the no-decay group (no_weight_decay(), :163-165)
+    mp = tiny_model(use_abs_pos_emb=True)
+    keys = list(mp.state_dict())
+    assert keys[:3] == ["cls_token", "mask_token", "pos_embed"] and tuple(mp.pos_embed.shape) == (1, mp.patch_embed.num_patches + 1, mp.embed_dim)
+    assert float(mp.pos_embed.abs().max()) > 0 and float(mp.pos_embed.abs().max()) <= mp.init_std + 1e-6       # trunc-normal on [-std, std]
     from uncertainty_vit_amd.modeling_cyclical import create_model
     with pytest.raises(RuntimeError):
         create_model("not_a_model")

@@ -237,3 +237,34 @@ def test_flag_gated_targets_and_variance_term(golden_dir):
                 check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
     for n in entries(fx, "post"):
         check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)
+
+
+def test_abs_pos_emb_case(golden_dir):
+    """`--abs_pos_emb`: pos_embed (1, N, C) added after the cls concat, in the no-decay group (modeling_cyclical.py:80-84,
+    163-165, 193-194): forward and two steps of the oracle against the reference."""
+    fx = np.load(os.path.join(golden_dir, "model_abspos.npz"))
+    img, dim, depth, heads, B, n_mask, steps = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1, use_abs_pos_emb=True)
+    shapes = vo.param_shapes(cfg)
+    assert [n for n in fx["names"].tolist() if not n.endswith("relative_position_index")] == list(shapes)     # state-dict order
+    assert "pos_embed" in fx["groups/no_decay"].tolist()
+    p = closed_form_state(shapes, gamma=0.1)
+    x0, m0 = closed_form_images("abspos/0", B, img), torch.from_numpy(fx["mask0"])
+    ends = vo.forward(p, cfg, x0, None, True, "end")
+    for i in range(depth):
+        check_entry(fx, f"fwd/end{i}", ends[i], RT, AT)
+    check_entry(fx, "fwd/student_masked", vo.forward(p, cfg, x0, m0, False), RT, AT)
+    hp = vo.StepHParams(target_layers=(1,))
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    for s in range(steps):
+        res = vo.train_step(p, ema, m, v, cfg, hp, closed_form_images(f"abspos/{s}", B, img), torch.from_numpy(fx[f"mask{s}"]), s + 1)
+        assert res.loss == pytest.approx(float(fx["loss"][s]), rel=2e-4)
+        assert res.grad_norm == pytest.approx(float(fx["grad_norm"][s]), rel=2e-3)
+        if s == 0:
+            assert set(entries(fx, "grad0")) == set(res.grads) and "pos_embed" in res.grads
+            for n in entries(fx, "grad0"):
+                check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
+    for n in entries(fx, "post"):
+        check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)

@@ -36,11 +36,11 @@ def put(out, key, t):
         out[key + "/sum"], out[key + "/samples"] = s, v
 
 
-def build(mc, img, dim, depth, heads, init_values):
+def build(mc, img, dim, depth, heads, init_values, abs_pos=False):
     model = mc.VisionTransformerForCyclicalTraining(
         img_size=img, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4,
         qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=init_values,
-        use_shared_rel_pos_bias=True, use_abs_pos_emb=False, drop_path_rate=0.0, attn_drop_rate=0.0)
+        use_shared_rel_pos_bias=True, use_abs_pos_emb=abs_pos, drop_path_rate=0.0, attn_drop_rate=0.0)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype == torch.float32}
     model.load_state_dict(closed_form_state(shapes, gamma=init_values), strict=False)
     return model
@@ -139,6 +139,35 @@ def gen_flag_case(mc, eng):
             put(out, "post/" + k, v)
     np.savez_compressed(os.path.join(OUT, "model_flags.npz"), **out)
     print("wrote flag case: loss", rec["loss"], "loss_var0", rec["loss_var0"], "gnorm", rec["grad_norm"])
+
+
+def gen_abs_pos_case(mc, eng):
+    """`--abs_pos_emb` (modeling_cyclical.py:80-84,193-194; off in every BASELINE config): forward + 2 steps, tiny model."""
+    img, dim, depth, heads, B, n_mask = 48, 128, 2, 2, 4, 4
+    model = build(mc, img, dim, depth, heads, 0.1, abs_pos=True)
+    names = list(model.state_dict().keys())
+    batches = [(closed_form_images(f"abspos/{s}", B, img), exact_masks(B, 9, n_mask, 800 + s)) for s in range(2)]
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, 2], dtype=np.int64), "names": np.array(names)}
+    model.eval()
+    with torch.no_grad():
+        ends = model(batches[0][0], None, True, layer_results="end")
+        stu = model(batches[0][0], batches[0][1], return_all_tokens=False)
+    for i, e in enumerate(ends):
+        put(out, f"fwd/end{i}", e)
+    put(out, "fwd/student_masked", stu)
+    model.train()
+    rec, grads, ema, groups = run_reference_steps(eng, model, batches, [1])
+    out["loss"], out["grad_norm"] = np.array(rec["loss"]), np.array(rec["grad_norm"])
+    out["groups/no_decay"] = np.array(groups["no_decay"])
+    for s, (_, bm) in enumerate(batches):
+        out[f"mask{s}"] = bm.numpy()
+    for k, v in grads.items():
+        put(out, "grad0/" + k, v)
+    for k, v in model.state_dict().items():
+        if v.dtype == torch.float32:
+            put(out, "post/" + k, v)
+    np.savez_compressed(os.path.join(OUT, "model_abspos.npz"), **out)
+    print("wrote abs-pos case: loss", rec["loss"], "gnorm", rec["grad_norm"])
 
 
 CURVE_LR = 1e-4   # constant; the README recipe warms up from 1e-6, 2e-3 from step 0 is chaotic on a tiny model
@@ -374,6 +403,8 @@ def main():
         gen_loss_curve(mc, eng)
     if a.only in (None, "vitb"):
         gen_vitb_spot(mc)
+    if a.only in (None, "abspos"):
+        gen_abs_pos_case(mc, eng)
     if a.only in (None, "flags"):
         gen_flag_case(mc, eng)
     if a.only in (None, "dvitb"):

@@ -603,3 +603,40 @@ int uvit_variance_loss_launch(const float* out, const int* count, float w, float
     hipLaunchKernelGGL(varloss_grad_kernel, grid, dim3(256), 0, s, out, count, scratch, w * loss_scale, margin, (bf16*)dout, Mmax, C);
     return uvit_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// Absolute position embedding (--abs_pos_emb; modeling_cyclical.py:80-84,193-194): x[b, n, :] += pos[n, :] after the cls
+// concat, and its gradient d pos[n, :] = sum_b dX[b, n, :].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, size_t n4, size_t per_sample4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ((float4*)x)[i];
+        const float4 p = ((const float4*)pos)[i % per_sample4];
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        ((float4*)x)[i] = a;
+    }
+}
+__global__ __launch_bounds__(256)
+void pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B, size_t per_sample4) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= per_sample4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+        const float4 d = ((const float4*)dx)[(size_t)b * per_sample4 + i];
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+    }
+    ((float4*)dpos)[i] = acc;
+}
+int uvit_add_pos_launch(float* x, const float* pos, int B, int N, int C, hipStream_t s) {
+    if (C % 4) return UVIT_ERR_SHAPE;
+    const size_t per = (size_t)N * C / 4, n4 = per * B;
+    hipLaunchKernelGGL(add_pos_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, x, pos, n4, per);
+    return uvit_check_launch();
+}
+int uvit_pos_bwd_launch(const float* dx, float* dpos, int B, int N, int C, hipStream_t s) {
+    if (C % 4) return UVIT_ERR_SHAPE;
+    const size_t per = (size_t)N * C / 4;
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, dx, dpos, B, per);
+    return uvit_check_launch();
+}

@@ -28,7 +28,7 @@
 struct LayerOff { size_t n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2;
                   size_t cqkvw, cqb, cvb, cprojw, cprojb; };   // two-stream model only
 struct Layout {
-    size_t cls, mask_tok, pew, peb, relt, normw, normb, lmw, lmb;
+    size_t cls, mask_tok, pew, peb, relt, normw, normb, lmw, lmb, pos;
     size_t ccls, cmask_tok, cpew, cpeb, clmw, clmb;          // two-stream model only
     LayerOff L[UVIT_MAX_DEPTH];
     size_t n_total, n_decay, n_live;     // [0, n_decay) decay | [n_decay, n_live) no-decay | [n_live, n_total) frozen
@@ -43,7 +43,8 @@ static int cfg_ok(const uvit_config* c) {
     if (c->embed_dim % 64 || c->mlp_hidden % 64 || c->patch_size % 8 || c->img_size % c->patch_size) return UVIT_ERR_SHAPE;
     if ((c->in_chans * c->patch_size * c->patch_size) % 64) return UVIT_ERR_SHAPE;
     const int g = c->img_size / c->patch_size;
-    if (g * g + 1 > 208 || c->batch < 1 || c->use_abs_pos_emb) return UVIT_ERR_SHAPE;
+    if (g * g + 1 > 208 || c->batch < 1) return UVIT_ERR_SHAPE;
+    if (c->use_abs_pos_emb && c->two_stream) return UVIT_ERR_SHAPE;      // the two-stream model has no position embedding (modeling_cyclical_dist.py:113-130)
     return UVIT_OK;
 }
 
@@ -86,6 +87,8 @@ static void build_layout(const uvit_config* c, Layout& lo) {
     lo.n_decay = off;
     // ---- no-decay group ----
     lo.cls = add("cls_token", {1, 1, C}, 0);
+    // 'pos_embed' (1, N, C) is 3-D but sits in the no_weight_decay() skip list (modeling_cyclical.py:163-165)
+    lo.pos = c->use_abs_pos_emb ? add("pos_embed", {1, g * g + 1, C}, 0) : (size_t)-1;
     lo.peb = add("patch_embed.proj.bias", {C}, 0);
     if (two) lo.cpeb = add("cov_patch_embed.proj.bias", {C}, 0);
     for (int i = 0; i < c->depth; ++i) {
@@ -484,6 +487,8 @@ static int embed(uvit_engine* e, const Weights& w, const int64_t* mask, float* x
         pe.mask_token = w.f + (st ? e->lo.cmask_tok : e->lo.mask_tok); pe.ldo = e->C; pe.patches = e->P;
         CHECK(GEMM_NT(EPI_PATCH, e->cols, w.b + (st ? e->lo.cpew : e->lo.pew), Bc * e->P, e->C, e->Kpe, e->Kpe, e->Kpe, &pe, s));
         CHECK(uvit_set_cls_launch(x, w.f + (st ? e->lo.ccls : e->lo.cls), nullptr, Bc, e->N, e->C, s));
+        // x = x + pos_embed (modeling_cyclical.py:193-194; --abs_pos_emb, off in every BASELINE config)
+        if (e->cfg.use_abs_pos_emb) CHECK(uvit_add_pos_launch(x, w.f + e->lo.pos, Bc, e->N, e->C, s));
     }
     return UVIT_OK;
 }
@@ -792,6 +797,7 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
         CHECK(uvit_colsum_launch(e->dpatch[st], C, 0, C, BP, RP(st ? lo.cpeb : lo.peb), NREP, e->n_nd, s));
         CHECK(GEMM_TN(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
     }
+    if (e->cfg.use_abs_pos_emb) CHECK(uvit_pos_bwd_launch(e->dXa, g + lo.pos, e->B, e->N, C, s));     // d pos_embed = sum_b dX[b]
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
         CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed

@@ -117,6 +117,8 @@ int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf1
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
 int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step,
                          hipStream_t s);
+int uvit_add_pos_launch(float* x, const float* pos, int B, int N, int C, hipStream_t s);
+int uvit_pos_bwd_launch(const float* dx, float* dpos, int B, int N, int C, hipStream_t s);
 int uvit_synth_batch_launch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,
                             uint32_t it, hipStream_t s);
 int uvit_poison_if_nonfinite_launch(const float* loss, float* dst, int* sticky, hipStream_t s);

@@ -142,7 +142,7 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         # options outside the data2vec pre-training hot path are rejected, not silently ignored
         unsupported = dict(qk_scale=qk_scale, attn_head_dim=attn_head_dim, gp_layer=gp_layer, gumbel_softmax=gumbel_softmax,
                            sinkformer=sinkformer, h_sto_trans=h_sto_trans, stosa=stosa, use_rel_pos_bias=use_rel_pos_bias,
-                           use_abs_pos_emb=use_abs_pos_emb)
+                           use_abs_pos_emb=use_abs_pos_emb and self._two_stream)   # the two-stream model has no pos_embed
         bad = [k for k, v in unsupported.items() if v]
         if bad or not qkv_bias or drop_rate:
             raise NotImplementedError(f"not on the MI355X hot path (SURVEY.md section 8): {bad or 'qkv_bias/drop_rate'}")
@@ -162,7 +162,9 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         self.init_std = init_std
         self.patch_embed = _PatchEmbedInfo(img_size, patch_size)
         self.stosa = False
-        self.pos_embed = None
+        self.use_abs_pos_emb = bool(use_abs_pos_emb)
+        if not self.use_abs_pos_emb:
+            self.pos_embed = None            # otherwise an arena view registered below (modeling_cyclical.py:80-84)
         ws = self.patch_embed.patch_shape[0]
 
         # ---- one flat arena; parameters are views (layout owned by the native library) ----
@@ -212,7 +214,8 @@ class VisionTransformerForCyclicalTraining(nn.Module):
     # ---- arena plumbing ----
     def _native_config(self, batch):
         return Config(self.img_size, self.patch_embed.patch_size[0], self.in_chans, self.embed_dim, self.depth,
-                      self.num_heads, self.mlp_hidden, 1 if getattr(self, "rel_pos_bias", True) is not None else 0, 0,
+                      self.num_heads, self.mlp_hidden, 1 if getattr(self, "rel_pos_bias", True) is not None else 0,
+                      1 if getattr(self, "use_abs_pos_emb", False) else 0,
                       batch, self.ln_eps, self.attn_drop_rate, self.drop_path_rate, 0, 1 if self._two_stream else 0)
 
     def _owner(self, name):
@@ -232,7 +235,7 @@ class VisionTransformerForCyclicalTraining(nn.Module):
         (ModelEmaV2 zips state-dict VALUES by position, engine_for_cyclical.py:183)."""
         def reorder(mod, order):
             mod._parameters = {k: mod._parameters[k] for k in order if k in mod._parameters}
-        reorder(self, ["cls_token", "cov_cls_token", "mask_token", "cov_mask_token"])
+        reorder(self, ["cls_token", "cov_cls_token", "mask_token", "cov_mask_token", "pos_embed"])
         self._modules = {k: self._modules[k] for k in ("patch_embed", "cov_patch_embed", "rel_pos_bias", "blocks", "norm",
                                                        "lm_head", "cov_lm_head") if k in self._modules}
         for blk in self.blocks:
@@ -303,7 +306,7 @@ class VisionTransformerForCyclicalTraining(nn.Module):
                     p.fill_(1.0)
                 elif name.endswith("relative_position_bias_table") or name.endswith("bias"):
                     p.zero_()
-                elif name.endswith("weight") or name in ("cls_token", "mask_token"):
+                elif name.endswith("weight") or name in ("cls_token", "mask_token", "pos_embed"):
                     trunc_normal_(p, std=self.init_std)
             for i in range(self.depth):
                 sd[f"blocks.{i}.attn.proj.weight"].div_(math.sqrt(2.0 * (i + 1)))
