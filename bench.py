@@ -34,7 +34,7 @@ GFLOP_BY_MODEL = {"beit_base_patch16_224": 140.698, "dist_beit_base_patch16_224"
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
 ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
-TRAFFIC_BYTES = 418_000_000     # PMC: 2 x FETCH_SIZE (185 MB) + WRITE_SIZE (233 MB, mean of teacher/student launches); profiles/round1_pmc_hbm_v10.txt
+TRAFFIC_BYTES = 408_000_000     # PMC: 2 x FETCH_SIZE (90.3 MB) + WRITE_SIZE (151 MB teacher / 302 MB student launch, mean 227 MB); profiles/round2_pmc_hbm.txt
 # the reference's OWN engine_for_cyclical.train_one_epoch timed in the build container (tools/time_reference.py; the
 # reference cannot travel to the GPU box): bs=4, 8 threads, 3 timed steps -- quoted beside the port's figure
 REFERENCE_ENGINE_BUILD_CONTAINER = {"img_per_s": 2.292, "s_per_step": 1.745, "threads": 8, "batch": 4, "timed_steps": 3,
