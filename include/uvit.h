@@ -94,6 +94,9 @@ typedef struct uvit_step_params {
     /* flag-gated arithmetic of the step (no BASELINE config switches it on): */
     int32_t layer_results_fc;         /* --layer_results fc: targets from the teacher's MLP-branch outputs (modeling_cyclical.py:199-205) */
     float var_w0, var_margin0;        /* variance term, engine_for_cyclical.py:130-139,161 (var_w0 <= 0: off) */
+    /* target-builder variants (engine_for_cyclical.py:94-118): affine-free batch norm over (B, T) per channel, instance norm
+     * over T per (sample, channel) on every target layer; instance norm of the layer average.  Base model only. */
+    int32_t target_batch_norm, target_instance_norm, post_target_instance_norm;
 } uvit_step_params;
 
 int uvit_version(void);

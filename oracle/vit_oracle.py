@@ -93,6 +93,9 @@ class StepHParams:
     ema_decay: float = 0.9998
     var_w0: float = 0.0          # weight of the variance term (engine_for_cyclical.py:130-139, 161)
     var_margin0: float = 0.5
+    target_batch_norm: bool = False           # engine_for_cyclical.py:94-104
+    target_instance_norm: bool = False
+    post_target_instance_norm: bool = False   # :112-115
 
 
 # --------------------------------------------------------------------------------------
@@ -321,14 +324,23 @@ def forward(p: Dict[str, Tensor], cfg: VitConfig, x: Tensor, mask: Optional[Tens
 
 
 def build_targets(layer_outs: List[Tensor], mask: Tensor, hp: StepHParams) -> Tensor:
-    """engine_for_cyclical.py:90-122 with the flags the configs use (no batch/instance norm):
-    per-layer affine-free LayerNorm (eps 1e-5), mean over layers, optional post LayerNorm,
-    gather the masked rows."""
+    """engine_for_cyclical.py:90-122: per layer [batch norm over (B, T) per channel] [instance norm over T per
+    (sample, channel)] (both affine-free, biased variance, eps 1e-5) [affine-free LayerNorm (eps 1e-5)]; mean over the
+    layers; [post instance norm] [post LayerNorm]; gather the masked rows."""
     C = layer_outs[0].shape[-1]
-    vals = [layer_outs[i] for i in hp.target_layers]
+    vals = [layer_outs[i].float() for i in hp.target_layers]
+    if hp.target_batch_norm or hp.target_instance_norm:
+        vals = [v.permute(0, 2, 1) for v in vals]                      # btc -> bct
+        if hp.target_batch_norm:
+            vals = [F.batch_norm(v, running_mean=None, running_var=None, training=True) for v in vals]
+        if hp.target_instance_norm:
+            vals = [F.instance_norm(v) for v in vals]
+        vals = [v.permute(0, 2, 1) for v in vals]
     if hp.target_layer_norm_last:
-        vals = [F.layer_norm(v.float(), (C,)) for v in vals]
+        vals = [F.layer_norm(v, (C,)) for v in vals]
     t = sum(vals) / len(hp.target_layers)
+    if hp.post_target_instance_norm:
+        t = F.instance_norm(t.permute(0, 2, 1).float()).permute(0, 2, 1)
     if hp.post_target_layer_norm:
         t = F.layer_norm(t.float(), (C,))
     return t.reshape(-1, C)[mask.flatten().bool()]

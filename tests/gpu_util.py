@@ -40,7 +40,7 @@ def native_trainer(model, lr=2e-3, wd=0.05, decay=0.9998):
 
 def native_steps(model, ema, opt, batches, target_layers, start=0, clip=3.0, l1_beta=2.0, decay=0.9998, l2_loss=False,
                  loss_scale=-1, post_target_layer_norm=True, stochastic=False, lam=1e-5, layer_results="end", var_w0=0.0,
-                 var_margin0=0.5):
+                 var_margin0=0.5, **target_flags):
     """Each batch through the product's train_one_epoch (one-iteration loader); returns per-step stats."""
     from uncertainty_vit_amd import engine_for_cyclical as eng, utils
     out = []
@@ -49,9 +49,8 @@ def native_steps(model, ema, opt, batches, target_layers, start=0, clip=3.0, l1_
         st = eng.train_one_epoch(model, ema, 0, decay, decay, target_layers, loader, opt, torch.device("cuda"), 0,
                                  utils.NativeScalerWithGradNormCount(), max_norm=clip, l1_beta=l1_beta, start_steps=start + s,
                                  layer_results=layer_results, var_w0=var_w0, var_margin0=var_margin0, loss_scale=loss_scale,
-                                 target_layer_norm_last=True,
-                                 post_target_layer_norm=post_target_layer_norm, l2_loss=l2_loss, stochastic=stochastic,
-                                 lambda_pretraining=lam)
+                                 **{"target_layer_norm_last": True, "post_target_layer_norm": post_target_layer_norm, **target_flags},
+                                 l2_loss=l2_loss, stochastic=stochastic, lambda_pretraining=lam)
         out.append(st)
     return out
 

@@ -299,3 +299,37 @@ def test_abs_pos_emb_forward_and_steps(golden_dir):
     assert_grads_close(grads, ref.grads, what="[abs-pos] ")
     st += native_steps(model, ema, opt, [(closed_form_images("abspos/1", B, img).cuda(), torch.from_numpy(fx["mask1"]).cuda())], [1], start=1)
     assert st[1]["loss"] == pytest.approx(float(fx["loss"][1]), rel=2e-2)
+
+
+TNORM_CASES = {   # the flag combinations of tests/golden/target_norms.npz (tools/gen_golden.py TARGET_NORM_CASES)
+    "bn":        dict(target_batch_norm=True, target_instance_norm=False, target_layer_norm_last=True, post_target_instance_norm=False, post_target_layer_norm=True),
+    "in":        dict(target_batch_norm=False, target_instance_norm=True, target_layer_norm_last=True, post_target_instance_norm=False, post_target_layer_norm=False),
+    "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=True),
+    "raw_pin":   dict(target_batch_norm=False, target_instance_norm=False, target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=False),
+}
+
+
+@pytest.mark.parametrize("case", list(TNORM_CASES))
+def test_batch_and_instance_norm_target_variants(golden_dir, case):
+    """`--target_batch_norm`, `--target_instance_norm`, `--no_target_layer_norm_last`, `--post_target_instance_norm`
+    (engine_for_cyclical.py:94-118): one step of the HIP path (dense target builder) per flag combination against the
+    reference's numbers (tests/golden/target_norms.npz) and, per tensor, the oracle."""
+    fx = np.load(os.path.join(golden_dir, "target_norms.npz"))
+    img, dim, depth, heads, B, n_mask, _ = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    model, sd0 = native_model(cfg)
+    ema, opt = native_trainer(model)
+    x, mask = closed_form_images("tnorm", B, img), torch.from_numpy(fx["mask"])
+    fl = TNORM_CASES[case]
+    st = native_steps(model, ema, opt, [(x.cuda(), mask.cuda())], [1, 2], **fl)
+    assert st[0]["loss"] == pytest.approx(float(fx[f"{case}/loss"]), rel=5e-3)
+    assert st[0]["grad_norm"] == pytest.approx(float(fx[f"{case}/grad_norm"]), rel=3e-2)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    p, e, m1, v1 = oracle_state(sd0)
+    ref = vo.train_step(p, e, m1, v1, cfg, vo.StepHParams(target_layers=(1, 2), **fl), x, mask, 1)
+    assert_grads_close(grads, ref.grads, what=f"[{case}] ")
+    for n in entries(fx, f"{case}/grad"):
+        key = f"{case}/grad/{n}/full"
+        if key in fx:
+            g, r = grads[n].float().cpu().double(), torch.from_numpy(np.asarray(fx[key])).double()
+            assert (g - r).norm() <= 2e-2 * r.norm(), (n, float((g - r).norm() / r.norm()))

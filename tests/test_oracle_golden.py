@@ -268,3 +268,30 @@ def test_abs_pos_emb_case(golden_dir):
                 check_entry(fx, "grad0/" + n, res.grads[n], 2e-3, 2e-7)
     for n in entries(fx, "post"):
         check_entry(fx, "post/" + n, p[n], 1e-3, 2e-5)
+
+
+def _tnorm_hp(case):
+    fl = {"bn": dict(target_batch_norm=True, target_layer_norm_last=True, post_target_layer_norm=True),
+          "in": dict(target_instance_norm=True, target_layer_norm_last=True, post_target_layer_norm=False),
+          "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False,
+                            post_target_instance_norm=True, post_target_layer_norm=True),
+          "raw_pin": dict(target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=False)}[case]
+    return vo.StepHParams(target_layers=(1, 2), **fl)
+
+
+@pytest.mark.parametrize("case", ["bn", "in", "bn_in_pin", "raw_pin"])
+def test_batch_and_instance_norm_target_variants(golden_dir, case):
+    """engine_for_cyclical.py:94-118 (batch norm over (B, T), instance norm over T, with / without the per-layer LayerNorm,
+    post instance norm): one step of the oracle per flag combination against the reference."""
+    fx = np.load(os.path.join(golden_dir, "target_norms.npz"))
+    img, dim, depth, heads, B, n_mask, _ = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    p = closed_form_state(vo.param_shapes(cfg), gamma=0.1)
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    res = vo.train_step(p, ema, m, v, cfg, _tnorm_hp(case), closed_form_images("tnorm", B, img), torch.from_numpy(fx["mask"]), 1)
+    assert res.loss == pytest.approx(float(fx[f"{case}/loss"]), rel=2e-4)
+    assert res.grad_norm == pytest.approx(float(fx[f"{case}/grad_norm"]), rel=2e-3)
+    for n in entries(fx, f"{case}/grad"):
+        check_entry(fx, f"{case}/grad/{n}", res.grads[n], 2e-3, 2e-7)

@@ -47,7 +47,7 @@ def build(mc, img, dim, depth, heads, init_values, abs_pos=False):
 
 
 def run_reference_steps(eng, model, batches, target_layers, lr=2e-3, wd=0.05, clip=3.0,
-                        l1_beta=2.0, decay=0.9998, layer_results="end", var_w0=0.0, var_margin0=0.5):
+                        l1_beta=2.0, decay=0.9998, layer_results="end", var_w0=0.0, var_margin0=0.5, tflags=None):
     import optim_factory
     import timm.utils as U
     ema = U.ModelEmaV2(model, decay=decay)
@@ -67,8 +67,8 @@ def run_reference_steps(eng, model, batches, target_layers, lr=2e-3, wd=0.05, cl
             max_norm=clip, l1_beta=l1_beta, log_writer=None, lr_scheduler=None, start_steps=s,
             lr_schedule_values=None, wd_schedule_values=None, l2_loss=False, layer_results=layer_results,
             var_w0=var_w0, var_w1=0.0, var_margin0=var_margin0, start_lr_decay_at_step=-1, loss_scale=-1, mask_dropout_prob=-1.0,
-            target_layer_norm_last=True, target_batch_norm=False, target_instance_norm=False,
-            post_target_instance_norm=False, post_target_layer_norm=True, stochastic=False)
+            stochastic=False, **(tflags or dict(target_layer_norm_last=True, target_batch_norm=False, target_instance_norm=False,
+                                                post_target_instance_norm=False, post_target_layer_norm=True)))
         rec["loss"].append(stats["loss"])
         rec["grad_norm"].append(float(stats["grad_norm"]))
         rec.setdefault("loss_var0", []).append(float(stats["loss_var0"]))
@@ -139,6 +139,32 @@ def gen_flag_case(mc, eng):
             put(out, "post/" + k, v)
     np.savez_compressed(os.path.join(OUT, "model_flags.npz"), **out)
     print("wrote flag case: loss", rec["loss"], "loss_var0", rec["loss_var0"], "gnorm", rec["grad_norm"])
+
+
+TARGET_NORM_CASES = {   # name -> the five target-builder flags of engine_for_cyclical.py:94-118
+    "bn":        dict(target_batch_norm=True, target_instance_norm=False, target_layer_norm_last=True, post_target_instance_norm=False, post_target_layer_norm=True),
+    "in":        dict(target_batch_norm=False, target_instance_norm=True, target_layer_norm_last=True, post_target_instance_norm=False, post_target_layer_norm=False),
+    "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=True),
+    "raw_pin":   dict(target_batch_norm=False, target_instance_norm=False, target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=False),
+}
+
+
+def gen_target_norm_cases(mc, eng):
+    """Batch- / instance-norm target variants (engine_for_cyclical.py:94-118; flags off in every BASELINE config): one
+    reference step per flag combination on a tiny model (10 tokens), loss + grad-norm + a few gradients."""
+    img, dim, depth, heads, B, n_mask = 48, 128, 3, 2, 6, 4
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, 1], dtype=np.int64), "cases": np.array(list(TARGET_NORM_CASES))}
+    x, mask = closed_form_images("tnorm", B, img), exact_masks(B, 9, n_mask, 900)
+    out["mask"] = mask.numpy()
+    for name, fl in TARGET_NORM_CASES.items():
+        model = build(mc, img, dim, depth, heads, 0.1)
+        model.train()
+        rec, grads, _, _ = run_reference_steps(eng, model, [(x, mask)], [1, 2], tflags=fl)
+        out[f"{name}/loss"], out[f"{name}/grad_norm"] = np.float64(rec["loss"][0]), np.float64(rec["grad_norm"][0])
+        for k in ("lm_head.weight", "blocks.2.mlp.fc2.weight", "blocks.0.attn.qkv.weight", "norm.weight"):
+            put(out, f"{name}/grad/{k}", grads[k])
+        print("target-norm case", name, "loss", rec["loss"][0], "gnorm", rec["grad_norm"][0])
+    np.savez_compressed(os.path.join(OUT, "target_norms.npz"), **out)
 
 
 def gen_abs_pos_case(mc, eng):
@@ -403,6 +429,8 @@ def main():
         gen_loss_curve(mc, eng)
     if a.only in (None, "vitb"):
         gen_vitb_spot(mc)
+    if a.only in (None, "tnorm"):
+        gen_target_norm_cases(mc, eng)
     if a.only in (None, "abspos"):
         gen_abs_pos_case(mc, eng)
     if a.only in (None, "flags"):

@@ -155,6 +155,7 @@ struct uvit_engine {
     float *dp_scales, *dp_rates;
     float *loss, *gnorm; double* sumsq;
     float* wl_scratch;     // Wasserstein loss: scalars + per-row distances
+    float *dense_v, *dense_acc; int *idrows, *idcount;   // dense target builder (batch / instance-norm target variants)
     float* var_scratch;    // variance term: column sums / centred squares (2 C + 16 floats)
     int* poisoned;         // sticky: set by the first step whose loss / gradient norm is not finite; AdamW and EMA then skip every step
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
@@ -227,6 +228,8 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->wl_scratch = b.take<float>(16 + BPp);
     e->poisoned = b.take<int>(64);
     e->var_scratch = b.take<float>(2 * C + 16);
+    e->dense_v = b.take<float>(BPp * C); e->dense_acc = b.take<float>(BPp * C);
+    e->idrows = b.take<int>(e->BP + 64); e->idcount = b.take<int>(64);
     e->tdesc = b.take<TransposeDesc>(7 * c.depth + 4);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
     e->grep = b.take<float>((size_t)NREP * e->n_nd);
@@ -333,6 +336,14 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     addT(e->lo.lmw, e->C, e->C);
     if (e->S == 2) addT(e->lo.clmw, e->C, e->C);
     e->n_tdesc = (int)td.size(); e->n_ttiles = tiles;
+    {
+        std::vector<int> idr(e->BP);
+        for (int i = 0; i < e->BP; ++i) idr[i] = i;
+        const int cnt = e->BP;
+        if (hipMemcpyAsync(e->idrows, idr.data(), idr.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(e->idcount, &cnt, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
+    }
     if (hipMemcpyAsync(e->dp_rates, rates.data(), rates.size() * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemcpyAsync(e->tdesc, td.data(), td.size() * sizeof(TransposeDesc), hipMemcpyHostToDevice, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
@@ -521,21 +532,46 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
             CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s));
             // `[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): a layer listed twice is summed twice and the
             // mean divides by len(target_layers); the host has already mapped negative indices and refused out-of-range ones
+            const bool dense = hp_targets->target_batch_norm || hp_targets->target_instance_norm ||
+                               hp_targets->post_target_instance_norm || !hp_targets->target_layer_norm_last;
+            if (dense && (e->S != 1 || Bc != e->B)) return UVIT_ERR_ARG;
             for (int k = 0; k < hp_targets->n_target_layers; ++k) {
                 if (hp_targets->target_layers[k] != l) continue;
-                if (!hp_targets->target_layer_norm_last) return UVIT_ERR_ARG;
-                for (int st = 0; st < e->S; ++st)       // --layer_results fc: the block's MLP-branch output x_out - x_mid
-                    CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
-                                                   Bc * e->P, e->C, 1e-5f, s,
-                                                   hp_targets->layer_results_fc ? e->tXM + (size_t)st * e->Mpad * e->C : nullptr));
+                const float* sub = hp_targets->layer_results_fc ? e->tXM : nullptr;     // --layer_results fc: x_out - x_mid
+                if (!dense) {
+                    for (int st = 0; st < e->S; ++st)
+                        CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
+                                                       Bc * e->P, e->C, 1e-5f, s, sub ? sub + (size_t)st * e->Mpad * e->C : nullptr));
+                } else {
+                    // all patch tokens of this layer -> [batch norm] -> [instance norm] -> [LayerNorm] -> accumulate
+                    CHECK(uvit_gather_patch_rows_launch(xout, sub, e->dense_v, Bc, e->P, e->C, s));
+                    if (hp_targets->target_batch_norm) CHECK(uvit_colnorm_launch(e->dense_v, 1, Bc * e->P, e->C, 1e-5f, s));
+                    if (hp_targets->target_instance_norm) CHECK(uvit_colnorm_launch(e->dense_v, Bc, e->P, e->C, 1e-5f, s));
+                    if (hp_targets->target_layer_norm_last)
+                        CHECK(uvit_target_accum_launch(e->dense_v, e->idrows, e->idcount, e->dense_acc, n_t == 0, Bc * e->P, e->C, 1e-5f, s));
+                    else CHECK(uvit_axpy_rows_launch(e->dense_acc, e->dense_v, n_t == 0, (size_t)Bc * e->P * e->C, s));
+                }
                 ++n_t;
             }
         }
     }
     if (teacher && hp_targets) {
         if (n_t != hp_targets->n_target_layers) return UVIT_ERR_ARG;     // an index outside [0, depth) reached the C ABI
-        for (int st = 0; st < e->S; ++st)
-            CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
+        const bool dense = hp_targets->target_batch_norm || hp_targets->target_instance_norm ||
+                           hp_targets->post_target_instance_norm || !hp_targets->target_layer_norm_last;
+        if (!dense) {
+            for (int st = 0; st < e->S; ++st)
+                CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
+        } else {
+            const bool pin = hp_targets->post_target_instance_norm != 0;
+            CHECK(uvit_target_finalize_launch(e->dense_acc, e->idcount, n_t, hp_targets->post_target_layer_norm && !pin, Bc * e->P, e->C, 1e-5f, s));
+            if (pin) {
+                CHECK(uvit_colnorm_launch(e->dense_acc, Bc, e->P, e->C, 1e-5f, s));
+                if (hp_targets->post_target_layer_norm)
+                    CHECK(uvit_target_finalize_launch(e->dense_acc, e->idcount, 1, 1, Bc * e->P, e->C, 1e-5f, s));
+            }
+            CHECK(uvit_gather_masked_rows_launch(e->dense_acc, e->rowidx, e->count, e->targets[0], Bc * e->P, e->P, e->C, s));
+        }
     }
     e->cur_B = Bc;
     return UVIT_OK;

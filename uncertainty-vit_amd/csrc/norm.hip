@@ -385,3 +385,96 @@ int uvit_reduce_replicas_launch(const float* rep, float* out, size_t n, int nrep
     hipLaunchKernelGGL(reduce_replicas_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, rep, out, n / 4, nrep, stride / 4);
     return uvit_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// Dense target builder for the batch- / instance-norm target variants (engine_for_cyclical.py:94-118; flags off in every
+// BASELINE config).  Those normalise over ALL tokens, so the masked-rows-only builder above cannot serve them: each
+// target layer is gathered into a dense [B*P, C] buffer (cls dropped), normalised per channel over (B, T) ("batch") and /
+// or per (sample, channel) over T ("instance"; both affine-free, biased variance, eps 1e-5), then accumulated.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void gather_patch_rows_kernel(const float* __restrict__ x, const float* __restrict__ sub, float* __restrict__ v, int B, int P, int C4) {
+    const size_t total = (size_t)B * P * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C4; const int c = (int)(i - row * C4);
+        const int b = (int)(row / P), p_ = (int)(row - (size_t)b * P);
+        const size_t src = ((size_t)b * (P + 1) + 1 + p_) * C4 + c;
+        float4 a = ((const float4*)x)[src];
+        if (sub) { const float4 q = ((const float4*)sub)[src]; a.x -= q.x; a.y -= q.y; a.z -= q.z; a.w -= q.w; }
+        ((float4*)v)[i] = a;
+    }
+}
+
+// one workgroup per (group of `rows` consecutive rows, 64 channels): v <- (v - mean_c) * rsqrt(var_c + eps), statistics over
+// the group's rows (biased variance, accumulated in fp64)
+__global__ __launch_bounds__(256)
+void colnorm_kernel(float* __restrict__ v, int rows, int C, float eps) {
+    __shared__ double red[2][4][64];
+    __shared__ float stat[2][64];
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float* base = v + (size_t)blockIdx.y * rows * C;
+    double s1 = 0.0, s2 = 0.0;
+    if (ch < C)
+        for (int r = ph; r < rows; r += 4) { const double a = base[(size_t)r * C + ch]; s1 += a; s2 += a * a; }
+    red[0][ph][threadIdx.x & 63] = s1; red[1][ph][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (ph == 0) {
+        const int l = threadIdx.x;
+        const double a = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+        const double q = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+        const double mean = a / rows, var = q / rows - mean * mean;
+        stat[0][l] = (float)mean; stat[1][l] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+    __syncthreads();
+    if (ch < C) {
+        const float mean = stat[0][threadIdx.x & 63], rstd = stat[1][threadIdx.x & 63];
+        for (int r = ph; r < rows; r += 4) { float* q = base + (size_t)r * C + ch; *q = (*q - mean) * rstd; }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void axpy_rows_kernel(float* __restrict__ acc, const float* __restrict__ v, int first, size_t n4) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ((const float4*)v)[i];
+        if (!first) { const float4 b = ((const float4*)acc)[i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        ((float4*)acc)[i] = a;
+    }
+}
+
+// out[i] = dense[patch row of token row rowidx[i]]  (rowidx holds b * (P + 1) + 1 + p in mask order)
+__global__ __launch_bounds__(256)
+void gather_masked_rows_kernel(const float* __restrict__ dense, const int* __restrict__ rowidx, const int* __restrict__ count,
+                               float* __restrict__ out, int Mmax, int P, int C4) {
+    const int n = min(*count, Mmax);
+    const size_t total = (size_t)n * C4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C4; const int c = (int)(i - r * C4);
+        const int tok = rowidx[r], b = tok / (P + 1), p_ = tok - b * (P + 1) - 1;
+        ((float4*)out)[i] = ((const float4*)dense)[((size_t)b * P + p_) * C4 + c];
+    }
+}
+
+static unsigned dense_grid(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+int uvit_gather_patch_rows_launch(const float* x, const float* sub, float* v, int B, int P, int C, hipStream_t s) {
+    if (C % 4) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_patch_rows_kernel, dim3(dense_grid((size_t)B * P * (C / 4))), dim3(256), 0, s, x, sub, v, B, P, C / 4);
+    return uvit_check_launch();
+}
+int uvit_colnorm_launch(float* v, int groups, int rows, int C, float eps, hipStream_t s) {
+    if (groups < 1 || rows < 1) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(colnorm_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, s, v, rows, C, eps);
+    return uvit_check_launch();
+}
+int uvit_axpy_rows_launch(float* acc, const float* v, int first, size_t n, hipStream_t s) {
+    if (n % 4) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(axpy_rows_kernel, dim3(dense_grid(n / 4)), dim3(256), 0, s, acc, v, first, n / 4);
+    return uvit_check_launch();
+}
+int uvit_gather_masked_rows_launch(const float* dense, const int* rowidx, const int* count, float* out, int Mmax, int P, int C,
+                                   hipStream_t s) {
+    if (C % 4) return UVIT_ERR_SHAPE;
+    hipLaunchKernelGGL(gather_masked_rows_kernel, dim3(dense_grid((size_t)Mmax * (C / 4))), dim3(256), 0, s, dense, rowidx, count, out,
+                       Mmax, P, C / 4);
+    return uvit_check_launch();
+}

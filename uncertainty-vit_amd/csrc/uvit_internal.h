@@ -95,6 +95,11 @@ int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count
                              int C, float eps, hipStream_t s, const float* sub = nullptr);   // sub: rows subtracted before the LayerNorm
 int uvit_variance_loss_launch(const float* out, const int* count, float w, float margin, float loss_scale, float* scratch,
                               float* loss, float* std_loss0_out, void* dout_bf16, int Mmax, int C, hipStream_t s);
+int uvit_gather_patch_rows_launch(const float* x, const float* sub, float* v, int B, int P, int C, hipStream_t s);
+int uvit_colnorm_launch(float* v, int groups, int rows, int C, float eps, hipStream_t s);
+int uvit_axpy_rows_launch(float* acc, const float* v, int first, size_t n, hipStream_t s);
+int uvit_gather_masked_rows_launch(const float* dense, const int* rowidx, const int* count, float* out, int Mmax, int P, int C,
+                                   hipStream_t s);
 int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,
                                 hipStream_t s);
 

@@ -154,7 +154,7 @@ def native_step(engine, reducer, samples, mask, hp):
 
 def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
                      post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5,
-                     depth=None):
+                     depth=None, target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False):
     hp = StepParams()
     if len(target_layers) > MAX_DEPTH:
         raise ValueError(f"at most {MAX_DEPTH} target layers")
@@ -170,6 +170,8 @@ def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_
     hp.n_target_layers = len(target_layers)
     hp.target_layer_norm_last = int(bool(target_layer_norm_last))
     hp.post_target_layer_norm = int(bool(post_target_layer_norm))
+    hp.target_batch_norm, hp.target_instance_norm = int(bool(target_batch_norm)), int(bool(target_instance_norm))
+    hp.post_target_instance_norm = int(bool(post_target_instance_norm))
     hp.l2_loss = int(bool(l2_loss))
     hp.l1_beta, hp.loss_scale = float(l1_beta), float(loss_scale)
     hp.clip_grad = float(max_norm) if max_norm else 0.0
@@ -220,16 +222,15 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     print(' <<<<<<<< layer_results >>>>>>>>', layer_results)
     print(' <<<<<<<< var_w0, var_w1 >>>>>>>>', var_w0, var_w1)
     # flags whose arithmetic is not on the configured hot path are refused, never approximated
-    if layer_results not in ('end', 'fc') or target_batch_norm or target_instance_norm or post_target_instance_norm \
-            or not target_layer_norm_last:
-        raise NotImplementedError("batch/instance-norm targets and targets without the per-layer layer-norm are not native "
-                                  "(README.md:11-25 recipe: layer-norm targets)")
+    if layer_results not in ('end', 'fc'):
+        raise NotImplementedError(f"--layer_results {layer_results}: the blocks return 'end' and 'fc' results (modeling_finetune.py:185-203)")
+    dense_targets = target_batch_norm or target_instance_norm or post_target_instance_norm or not target_layer_norm_last
     model.train()
     net = _unwrap(model)
     teacher = model_ema.module
-    if stochastic and (layer_results != 'end' or var_w0 > 0):
-        raise NotImplementedError("the two-stream step is native for layer_results='end', var_w0=0 (modeling_cyclical_dist.py:136-139 "
-                                  "collects only 'end' results)")
+    if stochastic and (layer_results != 'end' or var_w0 > 0 or dense_targets):
+        raise NotImplementedError("the two-stream step is native for layer_results='end', var_w0=0 and layer-norm targets "
+                                  "(modeling_cyclical_dist.py:136-139 collects only 'end' results)")
     if bool(stochastic) != bool(getattr(net, "_two_stream", False)):
         # the reference unpacks (mean, cov) pairs when stochastic (engine_for_cyclical.py:70,126): only the two-stream
         # model (dist_beit_base_patch16_224) returns them -- SURVEY.md F8
@@ -322,7 +323,8 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
             cur_decay = 0
         hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
                               post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining,
-                              depth=net.depth)
+                              depth=net.depth, target_batch_norm=target_batch_norm, target_instance_norm=target_instance_norm,
+                              post_target_instance_norm=post_target_instance_norm)
         if scalars is not None and step < len(scalars):
             assert scalars[step] == (hp.lr, hp.weight_decay, hp.ema_decay if do_ema else -1.0), (scalars[step], hp.lr, hp.weight_decay, hp.ema_decay)
             if sched_dev is None:

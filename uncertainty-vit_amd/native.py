@@ -52,7 +52,8 @@ class StepParams(C.Structure):
                 ("opt_step", C.c_int32), ("ema_decay", C.c_float), ("do_ema", C.c_int32), ("grad_scale", C.c_float),
                 ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float),
                 ("sched_dev", C.c_void_p), ("sched_len", C.c_int32), ("sched_index", C.c_int32),
-                ("layer_results_fc", C.c_int32), ("var_w0", C.c_float), ("var_margin0", C.c_float)]
+                ("layer_results_fc", C.c_int32), ("var_w0", C.c_float), ("var_margin0", C.c_float),
+                ("target_batch_norm", C.c_int32), ("target_instance_norm", C.c_int32), ("post_target_instance_norm", C.c_int32)]
 
 
 class WgradProblem(C.Structure):
