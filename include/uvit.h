@@ -159,8 +159,10 @@ int uvit_train_step(uvit_engine* e, const float* images, const int64_t* mask, co
  *   tn_variant: wgrad (TN) GEMM: 3 = auto (default), 1 = 256x256 staggered kernel, 0 = 128x128;
  *   tn_split_target: workgroups the wgrad token split aims for (default 512);
  *   wgrad_group_chunks: token chunks per output tile of uvit_op_wgrad_group (0 = cost model, default);
- *   nt_group: 256x256 NT kernel: column tiles walked per row tile in the XCD-aware tile order (0 = default). */
-typedef struct uvit_tuning { int32_t nt_variant, tn_variant, tn_split_target, wgrad_group_chunks, nt_group; } uvit_tuning;
+ *   nt_group: 256x256 NT kernel: column tiles walked per row tile in the XCD-aware tile order (0 = default).
+ *   nt_persist: 256x256 NT kernel with more tiles than CUs: 1 = one persistent workgroup per CU with the operand pipeline
+ *               running across its tiles (default), 0 = one workgroup per tile. */
+typedef struct uvit_tuning { int32_t nt_variant, tn_variant, tn_split_target, wgrad_group_chunks, nt_group, nt_persist; } uvit_tuning;
 void uvit_tuning_default(uvit_tuning* out);
 /* Replace the engine's tuning (values outside the lists above are refused with UVIT_ERR_ARG). */
 int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t);

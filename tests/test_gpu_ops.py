@@ -145,6 +145,31 @@ def test_gemm_nt_qkv_gelu_resid_dgelu_patch(L, variant, nb, tokens, Cd, Pn):
         _epilogue_modes(L, nb, tokens, Cd, Pn)
 
 
+def test_gemm_nt_persistent_workgroups(L):
+    """gemm_nt256_kernel<MODE, 4, PERSIST>: one workgroup per CU walks several tiles with the operand pipeline running across
+    them (the next tile's first K-tiles are fetched during the current tile's last ones, the epilogue stages through its own
+    LDS region).  Every fused epilogue at a size where each GEMM has more tiles than CUs; then, against one workgroup per
+    tile, bit-identical results for an odd K-tile count (the LDS buffer parity flips from tile to tile), a ragged last row
+    tile and the minimum K, with a race screen."""
+    with tuned(nt_variant=1):
+        _epilogue_modes(L, 700, 100, 256, 140)
+    for M, N, K in [(25216, 3072, 192), (25216, 2304, 768), (70000, 256, 128), (25216, 768, 320)]:
+        a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
+        ref = a.float() @ w.float().t() + b
+        outs = []
+        for persist in (1, 0):
+            with tuned(nt_variant=1, nt_persist=persist):
+                out32 = torch.zeros(M, N, device="cuda")
+                ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+                outs.append(out32.clone())
+                for _ in range(5):
+                    out32.zero_()
+                    ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+                    assert torch.equal(out32, outs[-1]), "non-deterministic result: LDS pipeline race"
+        assert torch.equal(outs[0], outs[1]), (M, N, K)
+        close(outs[0], ref, rtol=2e-3, atol=2e-3, what=f"persistent {M}x{N}x{K}")
+
+
 def test_gemm_nt_row_split_of_a_nearly_empty_last_round(L):
     """Auto dispatch sends the row tiles that overflow whole rounds of 256x256 tiles (fc2: 297 tiles on 256 CUs) to the
     128x128 kernel: the residual epilogue's per-sample drop-path scale must keep indexing by the global row."""

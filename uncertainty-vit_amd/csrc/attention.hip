@@ -40,6 +40,24 @@ __device__ __forceinline__ void load_image(char* img, const bf16* src, size_t st
     }
 }
 
+// One 1-KiB LDS-DMA piece (global_load_lds, 16 B per lane, no VGPR round trip): rows 8 rb .. 8 rb + 7 of a [rows][64] bf16
+// source land in the swizzled image -- lane l writes LDS byte rb * 1024 + 16 l = img_off(row, chunk) for row = 8 rb + (l >> 3),
+// chunk = (l & 7) ^ (row & 7), so the swizzle is applied on the SOURCE side.  Rows >= n_valid re-read row n_valid - 1 (the DMA
+// cannot zero-fill): the user must mask padded rows arithmetically (the forward's -1e30 bias columns give p = 0 for padded
+// keys, and 0 x finite = 0 in P.V), so they only need to be finite.  `img` and `rb` must be wave-uniform.
+__device__ __forceinline__ void dma_rows8(char* img, int rb, const bf16* src, size_t stride, int n_valid, int lane) {
+    const int row = 8 * rb + (lane >> 3);
+    const int chunk = (lane & 7) ^ (lane >> 3);
+    const int r = row < n_valid ? row : n_valid - 1;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)r * stride + chunk * 8), LDS_PTR(void, img + rb * 1024), 16, 0, 0);
+}
+#define IMG_PIECES (ROWS_PAD / 8)          // 28 DMA pieces per image
+
+// After an explicit `s_waitcnt vmcnt(0)`: tell the compiler's wait-count tracking that a prefetched register HAS landed (it inserts
+// its own, by then free, wait in front of this use).  Without it the first real use -- on the far side of a loop back-edge and
+// behind newly issued stores, which the in-order vmcnt cannot skip -- waits for those as well.
+__device__ __forceinline__ void landed(bf16x8& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ bf16x8 row_frag(const char* img, int row, int chunk) {
     return *(const bf16x8*)(img + img_off(row, chunk));
 }
@@ -104,24 +122,30 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + IMG_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
     const bf16* base = qkv + (size_t)b * N * ld + h * HD;
-    load_image(kimg, base + C, ld, N, tid, NW * 64);
-    load_image(vimg, base + 2 * C, ld, N, tid, NW * 64);
-    __syncthreads();
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-
-    // the Q fragments of a wave's next tile are fetched while it works on the current one
+    // The Q fragments of a wave's first tile are requested first (the tile loop needs them before anything else), then the K / V
+    // images by LDS-DMA, 56 pieces of 8 rows over the NW waves (round 2: in-kernel stamps showed 8.5-12k of a workgroup's ~32k
+    // cycles in the register-staged image load and another ~4k waiting for Q behind it; tools/stamp_attn.py).
     bf16x8 qn[2];
     {
         const int q0 = wave * 16 + li, qr0 = q0 < N ? q0 : N - 1;
         qn[0] = *(const bf16x8*)(base + (size_t)qr0 * ld + g * 8);
         qn[1] = *(const bf16x8*)(base + (size_t)qr0 * ld + 32 + g * 8);
     }
+    for (int p = wave; p < 2 * IMG_PIECES; p += NW) {
+        const int img = p / IMG_PIECES, rb = p - img * IMG_PIECES;
+        dma_rows8(smem + img * IMG_BYTES, rb, base + (size_t)(1 + img) * C, ld, N, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(qn[0]); landed(qn[1]);
+    __syncthreads();
+    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
+
     for (int qt = wave; qt < nt; qt += NW) {
         const int q = qt * 16 + li;
         bf16x8 qf[2] = {qn[0], qn[1]};
@@ -207,6 +231,9 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
                 }
             }
         }
+        // the next tile's Q fragments were requested a whole tile ago: mark them landed before this tile's stores are issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(qn[0]); landed(qn[1]);
         if (q < N) {
             const float f = inv_keep / sum;
             bf16* dst = out + ((size_t)b * N + q) * C + h * HD + 4 * g;

@@ -376,17 +376,17 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
 static int tune_from_abi(const uvit_tuning* t, GemmTune& g) {
     if (!t) { g = GemmTune(); return UVIT_OK; }
     if ((t->nt_variant != 0 && t->nt_variant != 1 && t->nt_variant != 3 && t->nt_variant != 5 && t->nt_variant != 6 && t->nt_variant != 7) ||
-        (t->tn_variant != 0 && t->tn_variant != 1 && t->tn_variant != 3) || t->tn_split_target < 0 || t->wgrad_group_chunks < 0 || t->nt_group < 0 || t->nt_group > 64)
+        (t->tn_variant != 0 && t->tn_variant != 1 && t->tn_variant != 3) || t->tn_split_target < 0 || t->wgrad_group_chunks < 0 || t->nt_group < 0 || t->nt_group > 64 || (t->nt_persist != 0 && t->nt_persist != 1))
         return UVIT_ERR_ARG;
     g.nt_variant = t->nt_variant; g.tn_variant = t->tn_variant;
-    g.tn_target = t->tn_split_target > 0 ? t->tn_split_target : 512; g.group_chunks = t->wgrad_group_chunks; g.nt_group = t->nt_group;
+    g.tn_target = t->tn_split_target > 0 ? t->tn_split_target : 512; g.group_chunks = t->wgrad_group_chunks; g.nt_group = t->nt_group; g.nt_persist = t->nt_persist;
     return UVIT_OK;
 }
 
 extern "C" void uvit_tuning_default(uvit_tuning* out) {
     if (!out) return;
     const GemmTune d;
-    out->nt_variant = d.nt_variant; out->tn_variant = d.tn_variant; out->tn_split_target = d.tn_target; out->wgrad_group_chunks = d.group_chunks; out->nt_group = d.nt_group;
+    out->nt_variant = d.nt_variant; out->tn_variant = d.tn_variant; out->tn_split_target = d.tn_target; out->wgrad_group_chunks = d.group_chunks; out->nt_group = d.nt_group; out->nt_persist = d.nt_persist;
 }
 
 extern "C" int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t) {

@@ -278,10 +278,10 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
 }
 
 // NB blocks of one wave: ACC(b, ct) names the accumulator of block b, column sub-tile ct; MB(b) its first row.
-#define EPI_RUN(MODE, NB, region, nb_, ACC, MB) do { \
+#define EPI_RUN_B(MODE, NB, region, nb_, ACC, MB, WBYTES) do { \
         const EpiCols<MODE> cols_ = epi_cols<MODE>(epi, (nb_), lane, N); \
         constexpr int SLOT_ = stage_f32<MODE>() ? EPI_SLOT_F32 : EPI_SLOT_BF16; \
-        constexpr int GRP_ = EPI_WAVE_BYTES / SLOT_ < (NB) ? EPI_WAVE_BYTES / SLOT_ : (NB); \
+        constexpr int GRP_ = (WBYTES) / SLOT_ < (NB) ? (WBYTES) / SLOT_ : (NB); \
         _Pragma("unroll") for (int b0_ = 0; b0_ < (NB); b0_ += GRP_) { \
             EpiPre<MODE> pre_[GRP_]; \
             _Pragma("unroll") for (int b_ = 0; b_ < GRP_; ++b_) if (b0_ + b_ < (NB)) pre_[b_] = epi_prefetch<MODE>(epi, lane, MB(b0_ + b_), (nb_), M, N); \
@@ -292,6 +292,7 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
                 epi_flush<MODE>(epi, cols_, (region) + b_ * SLOT_, lane, MB(b0_ + b_), (nb_), M, N, pre_[b_]); \
             epi_sync(); \
         } } while (0)
+#define EPI_RUN(MODE, NB, region, nb_, ACC, MB) EPI_RUN_B(MODE, NB, region, nb_, ACC, MB, EPI_WAVE_BYTES)
 
 // ------------------------------------------------------------------------------------------
 // NT kernel
@@ -422,63 +423,130 @@ void gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int 
 // are ONE round where 256-row tiles need 297 = 1.16 rounds).  For MT = 5 an A half-tile holds 160 rows in a 192-row
 // (24 KiB) slot so that every wave still issues whole LDS-DMA instructions (3 per half-tile; the last 32 rows are
 // padding): LDS = 2 x (24 + 24 + 16 + 16) KiB = 160 KiB, and the counted waits become LA = 3, LB = 2 loads per thread.
-template <int MODE, int MT>
+// Diagnostic build only (-DGEMM_STAMP, tools/stamp_gemm.py): per-workgroup s_memtime stamps + the hardware id of the CU, to
+// lay the tiles of one launch out on a per-CU time line.  Never defined for libuvit.so.
+#if defined(GEMM_STAMP) || defined(GEMM_DEBUG)
+int uvit_gemm_nt_launch(int, const void*, const void*, int, int, int, int, int, const GemmEpi*, hipStream_t, const GemmTune*, int*);
+extern "C" int uvit_debug_gemm_nt(int mode, int variant, const void* A, const void* W, int M, int N, int K, void* out, void* out2,
+                                  const float* bias, const float* resid, const float* gamma, void* stream) {
+    GemmEpi e; e.out = out; e.out2 = out2; e.bias = bias; e.resid = resid; e.gamma = gamma; e.ldo = N; e.tokens = 197;
+    GemmTune t; t.nt_variant = variant % 100; t.nt_persist = variant < 100;
+    return uvit_gemm_nt_launch(mode, A, W, M, N, K, K, K, &e, (hipStream_t)stream, &t, nullptr);
+}
+#endif
+#ifdef GEMM_STAMP
+__device__ unsigned long long g_gemm_stamps[4096 * 8];
+#define GSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_gemm_stamps[blockIdx.x * 8 + (i)] = t_; } while (0)
+// persistent workgroups: stamps of tile `seq` (0..7) of workgroup blockIdx.x < 256 at [2048 + blockIdx.x * 8 + seq] * 8 + i
+#define GSTAMP_P(seq, i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (threadIdx.x == 0 && blockIdx.x < 256 && (seq) < 8) g_gemm_stamps[(2048 + blockIdx.x * 8 + (seq)) * 8 + (i)] = t_; } while (0)
+#define GSTAMP_ID() do { if (threadIdx.x == 0 && blockIdx.x < 4096) { \
+        g_gemm_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); \
+        g_gemm_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); } } while (0)
+extern "C" int uvit_debug_gemm_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define GSTAMP(i)
+#define GSTAMP_P(seq, i)
+#define GSTAMP_ID()
+#endif
+
+// PERSIST (MT = 4 only): one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... and the operand pipeline runs ACROSS tiles:
+// the loads the schedule would issue for K-tiles nk, nk + 1 of a tile fetch K-tiles 0, 1 of the workgroup's NEXT tile, so when the
+// K loop ends the next tile's prologue is already in LDS.  The epilogue stages through its own 32 KiB (4 KiB per wave) behind
+// the operand buffers, the next K loop starts while its stores are still in flight, and no workgroup is retired between tiles.
+// What that removes per tile (tools/stamp_gemm.py, fc1 shape, K = 768: K loop 35.0k cycles, epilogue 5.3k (bf16) / 16.5k
+// (GELU + GELU')): the prologue wait for the first operands (3.7k / 4.9k) and the gap between a workgroup's last store and the
+// next workgroup's first instruction (3.9k / 10.5k: store drain + dispatch).
+// vmcnt is one in-order counter for loads and stores: every load the next tile's first K-tile needs is OLDER than the epilogue's
+// stores and is waited for (vmcnt(0)) before the first store is issued, so K-tile 0 of a later tile needs no counted wait at all;
+// from K-tile 1 on the counted waits are the steady-state ones (a wait then also covers the stores issued before its loads).
+#define TP_EPI_BYTES 4096                              // persistent kernel: epilogue staging per wave
+#define TP_LDS_BYTES (T_LDS_BYTES + 8 * TP_EPI_BYTES)  // 160 KiB
+
+template <int MODE, int MT, bool PERSIST>
 __global__ __launch_bounds__(T_THREADS, 2)
 void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K,
                         int lda, int ldw, GemmEpi epi) {
+    static_assert(!PERSIST || MT == 4, "the 320-row tile leaves no LDS for a separate epilogue region");
     constexpr int BM_ = 64 * MT;                       // tile rows
     constexpr int AH_ROWS = 32 * MT;                   // rows of one A half-tile
     constexpr int LA = MT == 4 ? 2 : 3;                // LDS-DMA instructions per wave per A half-tile
     constexpr int A_HALF = LA * 8 * 1024;              // its LDS slot
     constexpr int BUF = 2 * A_HALF + 2 * HALF_BYTES;   // one K-tile buffer: [AL | AH | BL | BH]
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef GEMM_DESYNC
+    // experiment: a third of the first-round workgroups start half a tile period late (those CUs end up with one tile fewer)
+    if (blockIdx.x < 256 && (blockIdx.x >> 3) % 3 == GEMM_DESYNC_SET) {
+        const long long t0 = __builtin_amdgcn_s_memtime(), d = (long long)GEMM_DESYNC * (K / BK);
+        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    GSTAMP(0); GSTAMP_ID();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = N / T_BN, tiles_m = (M + BM_ - 1) / BM_;
-    int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int gmax = epi.ngroup > 0 ? epi.ngroup : 6;   // column tiles walked per row tile before moving to the next row tile
-    int gw = tiles_n <= gmax ? tiles_n : (tiles_n + ((tiles_n + gmax - 1) / gmax) - 1) / ((tiles_n + gmax - 1) / gmax);
-    int tn0 = 0;
-    while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
-    const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
-    const int m0 = tm * BM_, n0 = tn * T_BN;
+    const int tiles_n = N / T_BN, tiles_m = (M + BM_ - 1) / BM_, ntiles = tiles_m * tiles_n;
     const int wm = wave >> 2, wn = wave & 3;
     const int g = lane >> 4, li = lane & 15;
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    // 32-bit element offsets from the (scalar) base pointers keep the loader at LA + LA + 2 + 2 VGPRs
-    uint32_t srcA[2][LA], srcB[2][2];                  // [AL, AH][instruction], [BL, BH][instruction]
+    // tile order: XCD-contiguous chunks (T1) of the VIRTUAL block id (a persistent workgroup's ids blockIdx.x + k gridDim.x stay on
+    // its XCD because the grid is a multiple of 8), column tiles grouped per row tile
+    auto tile_origin = [&](int vb, int& m0_, int& n0_) {
+        int bid = xcd_remap(vb, ntiles);
+        const int gmax = epi.ngroup > 0 ? epi.ngroup : 6;   // column tiles walked per row tile before moving to the next row tile
+        int gw = tiles_n <= gmax ? tiles_n : (tiles_n + ((tiles_n + gmax - 1) / gmax) - 1) / ((tiles_n + gmax - 1) / gmax);
+        int tn0 = 0;
+        while (bid >= tiles_m * gw) { bid -= tiles_m * gw; tn0 += gw; gw = min(gw, tiles_n - tn0); }
+        const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
+        m0_ = tm * BM_; n0_ = tn * T_BN;
+    };
+    // 32-bit element offsets from the (scalar) base pointers keep the loader at LA + LA + 2 + 2 VGPRs per tile
+    struct TileSrc { uint32_t a[2][LA], b[2][2]; };    // [AL, AH][instruction], [BL, BH][instruction]
+    auto tile_src = [&](int m0_, int n0_, TileSrc& ts) {
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-        int r = (j * 8 + wave) * 8 + srow;             // row inside the half-tile slot (rows >= AH_ROWS are padding)
-        r = r < AH_ROWS ? r : AH_ROWS - 1;
-        int ra = m0 + r;            ra = ra < M ? ra : M - 1;
-        int rb = m0 + AH_ROWS + r;  rb = rb < M ? rb : M - 1;
-        srcA[0][j] = (uint32_t)ra * (uint32_t)lda + schunk * 8;
-        srcA[1][j] = (uint32_t)rb * (uint32_t)lda + schunk * 8;
-    }
+        for (int j = 0; j < LA; ++j) {
+            int r = (j * 8 + wave) * 8 + srow;         // row inside the half-tile slot (rows >= AH_ROWS are padding)
+            r = r < AH_ROWS ? r : AH_ROWS - 1;
+            int ra = m0_ + r;            ra = ra < M ? ra : M - 1;
+            int rb = m0_ + AH_ROWS + r;  rb = rb < M ? rb : M - 1;
+            ts.a[0][j] = (uint32_t)ra * (uint32_t)lda + schunk * 8;
+            ts.a[1][j] = (uint32_t)rb * (uint32_t)lda + schunk * 8;
+        }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (j * 8 + wave) * 8 + srow;
-        // a wave's 2 x 32 output columns are adjacent (BL row r <-> column 64 (r / 32) + r % 32, BH +32): full
-        // 128-B lines per row in the staged epilogue
-        const int cb = (r >> 5) * 64 + (r & 31);
-        srcB[0][j] = (uint32_t)(n0 + cb) * (uint32_t)ldw + schunk * 8;
-        srcB[1][j] = (uint32_t)(n0 + cb + 32) * (uint32_t)ldw + schunk * 8;
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int r = (j * 8 + wave) * 8 + srow;
+            // a wave's 2 x 32 output columns are adjacent (BL row r <-> column 64 (r / 32) + r % 32, BH +32): full
+            // 128-B lines per row in the staged epilogue
+            const int cb = (r >> 5) * 64 + (r & 31);
+            ts.b[0][j] = (uint32_t)(n0_ + cb) * (uint32_t)ldw + schunk * 8;
+            ts.b[1][j] = (uint32_t)(n0_ + cb + 32) * (uint32_t)ldw + schunk * 8;
+        }
+    };
+    int vb = blockIdx.x;
+    int m0, n0;
+    tile_origin(vb, m0, n0);
+    TileSrc cur, nxt;
+    tile_src(m0, n0, cur);
+    nxt = cur;
     const int nk = K / BK;
-    auto issue = [&](int kind, int t) {                // kind: 0 AL, 1 AH, 2 BL, 3 BH
-        if (t < nk) {
-            char* buf = smem + (t & 1) * BUF;
-            const uint32_t k0 = (uint32_t)t * BK;
+    int par = 0;                                       // LDS buffer of the current tile's K-tile 0 (alternates when nk is odd)
+    bool more = false;                                 // this workgroup has another tile after the current one
+    auto issue = [&](int kind, int t) {                // kind: 0 AL, 1 AH, 2 BL, 3 BH; t >= nk: K-tile t - nk of the next tile
+        const bool own = t < nk;
+        if (own || more) {
+            char* buf = smem + ((t + par) & 1) * BUF;
+            const uint32_t k0 = (uint32_t)(own ? t : t - nk) * BK;
             if (kind < 2) {
                 char* dst = buf + kind * A_HALF + wave * 1024;
 #pragma unroll
-                for (int j = 0; j < LA; ++j) glds16(A + (srcA[kind][j] + k0), dst + j * 8 * 1024);
+                for (int j = 0; j < LA; ++j) glds16(A + ((own ? cur.a[kind][j] : nxt.a[kind][j]) + k0), dst + j * 8 * 1024);
             } else {
                 char* dst = buf + 2 * A_HALF + (kind - 2) * HALF_BYTES + wave * 1024;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) glds16(W + (srcB[kind - 2][j] + k0), dst + j * 8 * 1024);
+                for (int j = 0; j < 2; ++j) glds16(W + ((own ? cur.b[kind - 2][j] : nxt.b[kind - 2][j]) + k0), dst + j * 8 * 1024);
             }
         }
     };
@@ -486,14 +554,6 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     const int a_off = (wm * 16 * MT + li) * 128, b_off = (wn * 32 + li) * 128;
 
     f32x4 acc[2][2][MT][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < MT; ++c)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[MT][2], b0f[2][2], b1f[2][2];
 
 #define LOAD_A(half_base) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { \
@@ -513,60 +573,99 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #define WAIT_AB() do { if constexpr (MT == 4) VM_WAIT(4); else VM_WAIT(5); } while (0)         /* LA + LB */
 #define WAIT_A() do { if constexpr (MT == 4) VM_WAIT(2); else VM_WAIT(3); } while (0)          /* LA */
 
-    // ---- prologue: AL0 BL0 BH0 AH0 AL1 BL1 (BH1, AH1 are issued in phases 0, 1 of tile 0)
+    // ---- prologue of the workgroup's first tile: AL0 BL0 BH0 AH0 AL1 BL1 (BH1, AH1 are issued in phases 0, 1 of K-tile 0)
     issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
     issue(0, 1); issue(2, 1);
     if (nk >= 2) WAIT_FULL(); else WAIT_AB();          // AL0, BL0 landed (younger: BH0 AH0 [AL1 BL1])
-    RAW_BARRIER();
-    if (wm == 1) RAW_BARRIER();                        // the stagger: wm = 1 runs one barrier behind
+    bool first = true;                                 // later tiles: everything the prologue loads has already landed
+#ifdef GEMM_STAMP
+    int seq = 0;
+#endif
 
-    for (int t = 0; t < nk; ++t) {
-        const char* buf = smem + (t & 1) * BUF;
-        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;
-        // ---- phase 0: quadrant (0,0) <- AL, BL
-        LOAD_B(b0f, buf + 2 * A_HALF);
-        LOAD_A(buf);
-        issue(3, t + 1);                               // BH(t+1): slot last read in phase 1 of tile t-1
-        if (has1) WAIT_FULL(); else WAIT_A();          // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
+    for (;;) {
+        if constexpr (PERSIST) {
+            more = vb + (int)gridDim.x < ntiles;
+            if (more) { int m1, n1; tile_origin(vb + gridDim.x, m1, n1); tile_src(m1, n1, nxt); }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < MT; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         RAW_BARRIER();
-        LDS_WAIT();
-        MMA(0, 0, b0f);
-        RAW_BARRIER();
-        // ---- phase 1: quadrant (0,1) <- BH
-        LOAD_B(b1f, buf + 2 * A_HALF + HALF_BYTES);
-        issue(1, t + 1);                               // AH(t+1): slot last read in phase 2 of tile t-1
-        if (has1) WAIT_FULL(); else VM_WAIT(0);        // AH(t) landed
-        RAW_BARRIER();
-        LDS_WAIT();
-        MMA(0, 1, b1f);
-        RAW_BARRIER();
-        // ---- phase 2: quadrant (1,1) <- AH
-        LOAD_A(buf + A_HALF);
-        issue(0, t + 2);                               // AL(t+2): slot last read in phase 0
-        RAW_BARRIER();
-        LDS_WAIT();
-        MMA(1, 1, b1f);
-        RAW_BARRIER();
-        // ---- phase 3: quadrant (1,0), no LDS read
-        issue(2, t + 2);                               // BL(t+2): slot last read in phase 0
-        if (has2) WAIT_FULL(); else if (has1) WAIT_AB();   // AL(t+1), BL(t+1) landed (younger: BH AH (t+1) [AL BL (t+2)])
-        RAW_BARRIER();
-        MMA(1, 0, b0f);
-        RAW_BARRIER();
+        GSTAMP(1); GSTAMP_P(seq, 1);
+        if (wm == 1) RAW_BARRIER();                    // the stagger: wm = 1 runs one barrier behind
+
+        for (int t = 0; t < nk; ++t) {
+            const char* buf = smem + ((t + par) & 1) * BUF;
+            const bool has1 = t + 1 < nk || more, has2 = t + 2 < nk || more;
+            const bool landed = !first && t == 0;      // K-tile 0 (and AL1, BL1) of a later tile: waited for before the epilogue's stores
+            // ---- phase 0: quadrant (0,0) <- AL, BL
+            LOAD_B(b0f, buf + 2 * A_HALF);
+            LOAD_A(buf);
+            issue(3, t + 1);                           // BH(t+1): slot last read in phase 1 of tile t-1
+            if (!landed) { if (has1) WAIT_FULL(); else WAIT_A(); }      // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
+            RAW_BARRIER();
+            LDS_WAIT();
+            MMA(0, 0, b0f);
+            RAW_BARRIER();
+            // ---- phase 1: quadrant (0,1) <- BH
+            LOAD_B(b1f, buf + 2 * A_HALF + HALF_BYTES);
+            issue(1, t + 1);                           // AH(t+1): slot last read in phase 2 of tile t-1
+            if (!landed) { if (has1) WAIT_FULL(); else VM_WAIT(0); }    // AH(t) landed
+            RAW_BARRIER();
+            LDS_WAIT();
+            MMA(0, 1, b1f);
+            RAW_BARRIER();
+            // ---- phase 2: quadrant (1,1) <- AH
+            LOAD_A(buf + A_HALF);
+            issue(0, t + 2);                           // AL(t+2): slot last read in phase 0
+            RAW_BARRIER();
+            LDS_WAIT();
+            MMA(1, 1, b1f);
+            RAW_BARRIER();
+            // ---- phase 3: quadrant (1,0), no LDS read
+            issue(2, t + 2);                           // BL(t+2): slot last read in phase 0
+            if (!landed) { if (has2) WAIT_FULL(); else if (has1) WAIT_AB(); }   // AL(t+1), BL(t+1) landed (younger: BH AH (t+1) [AL BL (t+2)])
+            RAW_BARRIER();
+            MMA(1, 0, b0f);
+            RAW_BARRIER();
+        }
+        if (wm == 0) RAW_BARRIER();                    // matches the trailing group's last barrier
+        GSTAMP(2); GSTAMP_P(seq, 2);
+
+#define ACC1(b, ct) acc[(b) / MT][(ct) >> 1][(b) % MT][(ct) & 1]
+#define MB1(b) (m0 + ((b) / MT) * AH_ROWS + wm * 16 * MT + ((b) % MT) * 16)
+        if constexpr (PERSIST) {
+            // the next tile's K-tile 0 + AL1 BL1 were issued during the last two K-tiles: land them BEFORE the first store
+            VM_WAIT(0);
+            GSTAMP_P(seq, 4);
+            EPI_RUN_B(MODE, 2 * MT, smem + T_LDS_BYTES + wave * TP_EPI_BYTES, n0 + wn * 64, ACC1, MB1, TP_EPI_BYTES);
+        } else {
+            EPI_RUN(MODE, 2 * MT, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
+        }
+#undef ACC1
+#undef MB1
+        GSTAMP(3); GSTAMP_P(seq, 3);
+        if (!PERSIST || !more) break;
+        vb += gridDim.x;
+        tile_origin(vb, m0, n0);
+        cur = nxt;
+        par ^= nk & 1;
+        first = false;
+#ifdef GEMM_STAMP
+        ++seq;
+#endif
     }
-    if (wm == 0) RAW_BARRIER();                        // matches the trailing group's last barrier
 #undef LOAD_A
 #undef LOAD_B
 #undef MMA
 #undef WAIT_FULL
 #undef WAIT_AB
 #undef WAIT_A
-
-#define ACC1(b, ct) acc[(b) / MT][(ct) >> 1][(b) % MT][(ct) & 1]
-#define MB1(b) (m0 + ((b) / MT) * AH_ROWS + wm * 16 * MT + ((b) % MT) * 16)
-    EPI_RUN(MODE, 2 * MT, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
-#undef ACC1
-#undef MB1
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1082,8 +1181,9 @@ static void gemm_init_impl() {
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
     allow_lds(gemm_nt_kernel<EPI_GELU_DG>); allow_lds(gemm_nt_kernel<EPI_MULAUX>);
-#define ALLOW256(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS_BYTES); } while (0)
+#define ALLOW256(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS_BYTES); \
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<MODE, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T5_LDS_BYTES); } while (0)
     ALLOW256(EPI_BF16); ALLOW256(EPI_QKV); ALLOW256(EPI_GELU); ALLOW256(EPI_RESID); ALLOW256(EPI_F32); ALLOW256(EPI_PATCH); ALLOW256(EPI_DGELU); ALLOW256(EPI_QKV_ELU); ALLOW256(EPI_GELU_DG); ALLOW256(EPI_MULAUX);
 #undef ALLOW256
 #define ALLOWR(MODE) do { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<MODE, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, r_lds_bytes(8)); \
@@ -1175,8 +1275,12 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     const int grid = variant == 1 ? ((M + bm - 1) / bm) * (N / T_BN) : ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const size_t lds = 4 * STAGE_BYTES;
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
-#define L(MODE) do { if (variant == 1 && mt == 5) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 5>), dim3(grid), dim3(T_THREADS), T5_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
-        else if (variant == 1) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+    // persistent form of the 256-row kernel whenever a CU would otherwise run several workgroups back to back
+    const int pgrid = g_num_cu & ~7;
+    const bool persist = variant == 1 && mt == 4 && tu.nt_persist && pgrid >= 8 && grid > pgrid;
+#define L(MODE) do { if (variant == 1 && mt == 5) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 5, false>), dim3(grid), dim3(T_THREADS), T5_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+        else if (persist) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4, true>), dim3(pgrid), dim3(T_THREADS), TP_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
+        else if (variant == 1) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4, false>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else hipLaunchKernelGGL(gemm_nt_kernel<MODE>, dim3(grid), dim3(GEMM_THREADS), lds, s, a, w, M, N, K, lda, ldw, *epi); } while (0)
     switch (mode) {
         case EPI_BF16: L(EPI_BF16); break;

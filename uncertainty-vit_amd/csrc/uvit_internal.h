@@ -34,6 +34,7 @@ struct GemmTune {
     int tn_target = 512;     // workgroups the wgrad split-K aims for (MI355X sweep: 512 beats 256..1536 on all four wgrad shapes)
     int group_chunks = 0;    // grouped wgrad: 0 = cost model, > 0 = forced token-chunk count
     int nt_group = 0;        // 256x256 NT kernel: column tiles per row-tile group of the tile order (0 = default 6)
+    int nt_persist = 1;      // 256x256 NT kernel, more tiles than CUs: persistent workgroups, operand pipeline across tiles
 };
 // tune == nullptr: defaults.  tail_rows_out (nullable) receives the rows that went to the row-split tail launch.
 int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,

@@ -72,7 +72,7 @@ class GemmEpilogue(C.Structure):
 class Tuning(C.Structure):
     """uvit_tuning (include/uvit.h): launch tuning passed per call / held by the engine."""
     _fields_ = [("nt_variant", C.c_int32), ("tn_variant", C.c_int32), ("tn_split_target", C.c_int32),
-                ("wgrad_group_chunks", C.c_int32), ("nt_group", C.c_int32)]
+                ("wgrad_group_chunks", C.c_int32), ("nt_group", C.c_int32), ("nt_persist", C.c_int32)]
 
     @classmethod
     def default(cls, **over):
