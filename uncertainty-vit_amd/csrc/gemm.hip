@@ -54,37 +54,48 @@ __device__ __forceinline__ ColVals load_cols(const GemmEpi& e, int n, int N) {
     return c;
 }
 
-// Exact (erf) GELU for bf16 outputs.  Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz-Stegun 7.1.25,
-//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3) exp(-z^2),  t = 1 / (1 + p z),  |error| <= 2.5e-5
-// i.e. |error(Phi)| <= 1.3e-5: two orders below the bf16 half-ulp of the outputs (2e-3 at 1).  The fused GELU epilogues
-// are VALU-bound (a K = 64 launch: 63 us against 42 us for the plain bf16 store of the same bytes), so the formulation
-// minimises instructions: everything is written in |x| (source modifiers are free), constants are folded, and gelu(x)
-// itself needs no sign select:  gelu(x) = max(x, 0) - |x| q,  q = Phi(-|x|) = 0.5 (a1 t + a2 t^2 + a3 t^3) exp(-x^2 / 2).
-//   q      : 1 fma + v_rcp (t), 2 mul + v_exp (gauss), 3 (Horner, 0.5 folded into a_i), 1 mul          = 9 ops
-//   gelu   : + max, fma                                                                                   = 11 ops
-//   gelu'  : + Phi(x) = x < 0 ? q : 1 - q (3 ops), Phi + (x / sqrt(2 pi)) gauss (2 ops)                   = 16 ops for both
-// (round 1: 7.1.26 with 5 Horner terms, an explicit erf sign select and cdf = 0.5 (1 + erf): 16 / 20 ops.)
-__device__ __forceinline__ void gelu_q(float x, float& q, float& gauss) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.33267257f, ax, 1.0f));          // p / sqrt 2 = 0.47047 * 0.70710678
-    const float w = ax * 0.84932180f;                                                      // sqrt(log2(e) / 2): exp(-x^2/2) = exp2(-w^2)
-    gauss = __builtin_amdgcn_exp2f(-w * w);
-    const float poly = t * (0.1740121f + t * (-0.0479399f + t * 0.3739278f));              // 0.5 * {a1, a2, a3}
-    q = poly * gauss;
+// Exact (erf) GELU and its derivative for bf16 outputs, two elements per instruction.
+// The fused GELU epilogues are VALU-bound: in-kernel stamps of the fc1 launch (tools/stamp_gemm.py) put 27.5k of a tile's 63k
+// cycles in the GELU + GELU' epilogue against 7k for a plain bf16 store, at 4 cycles per wave-instruction and two waves per
+// SIMD.  So the formulation minimises instruction ISSUES: no transcendental (v_rcp / v_exp cost two issue slots each), and
+// everything on v_pk_fma_f32 / v_pk_mul_f32, which process two fp32 values per lane in one slot:
+//     xc = clamp(x, -4, 4), u = xc^2
+//     Phi(x)   ~ 0.5 + xc P(u)          (P, R: degree-8 least-squares fits on Chebyshev nodes of [0, 16], tools/fit_gelu.py)
+//     gelu(x)  = x Phi(xc)              (x > 4: x (1 - 3e-5);  x < -4: |x| 3e-5)
+//     gelu'(x) ~ 0.5 + xc R(u)          (R fits (Phi(x) - 0.5) / x + phi(x), i.e. gelu' = Phi + x phi directly)
+// max |error| on [-4, 4], fp32 Horner: Phi 6.3e-6 (2.6e-5 with the clamp tail), gelu 2.5e-5, gelu' 8.0e-5; beyond the clamp gelu <= 2.1e-4 (|x| <= 8),
+// gelu' <= 5.5e-4 -- all far below the bf16 half-ulp of the outputs (2e-3 at 1).
+// Issue slots per element: clamp 1 + u 0.5 + P 4 + Phi 0.5 + gelu 0.5 = 6.5; gelu' + R 4 + 0.5 = 11 for both
+// (round 2 first half: Abramowitz-Stegun 7.1.25 with v_rcp + v_exp: 13 / 18 slots; round 1: 16 / 20 ops + 2 transcendentals).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define GELU_HORNER(acc, u, c8, c7, c6, c5, c4, c3, c2, c1, c0) do { \
+        acc = f32x2{c8, c8}; \
+        acc = __builtin_elementwise_fma(acc, u, f32x2{c7, c7}); acc = __builtin_elementwise_fma(acc, u, f32x2{c6, c6}); \
+        acc = __builtin_elementwise_fma(acc, u, f32x2{c5, c5}); acc = __builtin_elementwise_fma(acc, u, f32x2{c4, c4}); \
+        acc = __builtin_elementwise_fma(acc, u, f32x2{c3, c3}); acc = __builtin_elementwise_fma(acc, u, f32x2{c2, c2}); \
+        acc = __builtin_elementwise_fma(acc, u, f32x2{c1, c1}); acc = __builtin_elementwise_fma(acc, u, f32x2{c0, c0}); } while (0)
+#define GELU_P(acc, u) GELU_HORNER(acc, u, 8.08658365e-11f, -7.02476654e-09f, 2.72402532e-07f, -6.31025083e-06f, 9.90762748e-05f, \
+                                   -1.13498475e-03f, 9.88112355e-03f, -6.64164935e-02f, 3.98925811e-01f)
+#define GELU_R(acc, u) GELU_HORNER(acc, u, 9.78443275e-10f, -8.21882605e-08f, 3.03107588e-06f, -6.50489355e-05f, 9.08658221e-04f, \
+                                   -8.72635215e-03f, 5.84950522e-02f, -2.64895682e-01f, 7.97648736e-01f)
+__device__ __forceinline__ f32x2 gelu_clamp2(f32x2 x) {
+    return f32x2{__builtin_amdgcn_fmed3f(x.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x.y, -4.0f, 4.0f)};
 }
-__device__ __forceinline__ float gelu_fast(float x) {
-    float q, gs; gelu_q(x, q, gs);
-    return __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x), u = xc * xc;
+    f32x2 p; GELU_P(p, u);
+    return x * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
 }
-__device__ __forceinline__ void gelu_and_grad_fast(float x, float& gelu, float& grad) {
-    float q, gs; gelu_q(x, q, gs);
-    gelu = __builtin_fmaf(-fabsf(x), q, fmaxf(x, 0.f));
-    const float cdf = x < 0.f ? q : 1.0f - q;
-    grad = __builtin_fmaf(x * 0.39894228040143268f, gs, cdf);
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+    const f32x2 xc = gelu_clamp2(x), u = xc * xc;
+    f32x2 r; GELU_R(r, u);
+    return __builtin_elementwise_fma(xc, r, f32x2{0.5f, 0.5f});
 }
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-    float ge, gr; gelu_and_grad_fast(x, ge, gr);
-    return gr;
+__device__ __forceinline__ void gelu_and_grad_fast2(f32x2 x, f32x2& gelu, f32x2& grad) {
+    const f32x2 xc = gelu_clamp2(x), u = xc * xc;
+    f32x2 p, r; GELU_P(p, u); GELU_R(r, u);
+    gelu = x * __builtin_elementwise_fma(xc, p, f32x2{0.5f, 0.5f});
+    grad = __builtin_elementwise_fma(xc, r, f32x2{0.5f, 0.5f});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -209,16 +220,19 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
                 if (e.out2) *(bf16x8*)((bf16*)e.out2 + o) = v;
                 bf16x8 av;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = f2bf(gelu_fast(bf2f(v[j])));
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 ge = gelu_fast2(f32x2{bf2f(v[j]), bf2f(v[j + 1])});
+                    av[j] = f2bf(ge.x); av[j + 1] = f2bf(ge.y);
+                }
                 *(bf16x8*)((bf16*)e.out + o) = av;
             } else if constexpr (MODE == EPI_GELU_DG) {
                 // gelu(h) and gelu'(h) from one erf / exp evaluation of the bf16-rounded h; backward multiplies by out2
                 bf16x8 av, dv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float ge, gr; gelu_and_grad_fast(bf2f(v[j]), ge, gr);
-                    av[j] = f2bf(ge);
-                    dv[j] = f2bf(gr);
+                for (int j = 0; j < 8; j += 2) {
+                    f32x2 ge, gr; gelu_and_grad_fast2(f32x2{bf2f(v[j]), bf2f(v[j + 1])}, ge, gr);
+                    av[j] = f2bf(ge.x); av[j + 1] = f2bf(ge.y);
+                    dv[j] = f2bf(gr.x); dv[j + 1] = f2bf(gr.y);
                 }
                 if (e.out2) *(bf16x8*)((bf16*)e.out2 + o) = dv;
                 *(bf16x8*)((bf16*)e.out + o) = av;
@@ -238,9 +252,11 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
             const bf16x8 h = pre.h[i];
             bf16x8 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = f2bf(lo[j] * (MODE == EPI_DGELU ? gelu_grad_fast(bf2f(h[j])) : bf2f(h[j])));
-                v[4 + j] = f2bf(hi[j] * (MODE == EPI_DGELU ? gelu_grad_fast(bf2f(h[4 + j])) : bf2f(h[4 + j])));
+            for (int j = 0; j < 4; j += 2) {
+                f32x2 ml = {bf2f(h[j]), bf2f(h[j + 1])}, mh = {bf2f(h[4 + j]), bf2f(h[5 + j])};
+                if constexpr (MODE == EPI_DGELU) { ml = gelu_grad_fast2(ml); mh = gelu_grad_fast2(mh); }
+                v[j] = f2bf(lo[j] * ml.x); v[j + 1] = f2bf(lo[j + 1] * ml.y);
+                v[4 + j] = f2bf(hi[j] * mh.x); v[5 + j] = f2bf(hi[j + 1] * mh.y);
             }
             *(bf16x8*)((bf16*)e.out + o) = v;
         }
@@ -529,7 +545,7 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     int m0, n0;
     tile_origin(vb, m0, n0);
     TileSrc cur, nxt;
-    tile_src(m0, n0, cur);
+    if constexpr (MT != 5) tile_src(m0, n0, cur);
     nxt = cur;
     const int nk = K / BK;
     int par = 0;                                       // LDS buffer of the current tile's K-tile 0 (alternates when nk is odd)
@@ -542,11 +558,38 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
             if (kind < 2) {
                 char* dst = buf + kind * A_HALF + wave * 1024;
 #pragma unroll
-                for (int j = 0; j < LA; ++j) glds16(A + ((own ? cur.a[kind][j] : nxt.a[kind][j]) + k0), dst + j * 8 * 1024);
+                for (int j = 0; j < LA; ++j) {
+                    uint32_t off;
+                    if constexpr (MT == 5) {
+                        // the 320-row tile sits at the 256-register limit: its operand offsets are recomputed per DMA instruction
+                        // (the VALU is idle in the K loop) instead of living in 10 VGPRs, which spilled inside the loop
+                        int sr = srow;
+                        asm volatile("" : "+v"(sr));       // opaque: keeps the recomputation inside the loop (no hoisting back into registers)
+                        int r = (j * 8 + wave) * 8 + sr;
+                        r = r < AH_ROWS ? r : AH_ROWS - 1;
+                        int ra = m0 + kind * AH_ROWS + r;  ra = ra < M ? ra : M - 1;
+                        off = (uint32_t)ra * (uint32_t)lda + schunk * 8;
+                    } else {
+                        off = own ? cur.a[kind][j] : nxt.a[kind][j];
+                    }
+                    glds16(A + (off + k0), dst + j * 8 * 1024);
+                }
             } else {
                 char* dst = buf + 2 * A_HALF + (kind - 2) * HALF_BYTES + wave * 1024;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) glds16(W + ((own ? cur.b[kind - 2][j] : nxt.b[kind - 2][j]) + k0), dst + j * 8 * 1024);
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t off;
+                    if constexpr (MT == 5) {
+                        int sr = srow;
+                        asm volatile("" : "+v"(sr));
+                        const int r = (j * 8 + wave) * 8 + sr;
+                        const int cb = (r >> 5) * 64 + (r & 31) + (kind - 2) * 32;
+                        off = (uint32_t)(n0 + cb) * (uint32_t)ldw + schunk * 8;
+                    } else {
+                        off = own ? cur.b[kind - 2][j] : nxt.b[kind - 2][j];
+                    }
+                    glds16(W + (off + k0), dst + j * 8 * 1024);
+                }
             }
         }
     };
@@ -1223,9 +1266,13 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     const bool ring_ok = (N % R_BN) == 0 && M >= 128 && K >= 64 && (K % R_BK) == 0 &&
                          (size_t)M * lda < 0xFFFFFFFFull && (size_t)N * ldw < 0xFFFFFFFFull;
     // auto: the residual epilogue (fp32 stream read + write + bf16 branch copy: the heaviest epilogue per flop) on narrow
-    // outputs runs ~5 % faster on the ring kernel, whose two workgroups per CU overlap one's epilogue with the other's K loop
-    // (tools/bench_epilogue.py: N = 768, K = 768: 83.7 vs 88.6 us; K = 3072: 162 vs 170 us)
-    const bool auto_ring = nt_variant == 3 && mode == EPI_RESID && ring_ok && N <= 1024 && M >= 160 * 8;
+    // outputs goes to the ring kernel, whose two workgroups per CU overlap one's epilogue with the other's K loop -- unless the
+    // 320-row tiles of the staggered kernel fill the CUs in ONE round (>= 85 % of them busy), where its stronger K loop wins
+    // (tools/bench_gemm_variants.py, M = 25216, N = 768: K = 3072 122.8 vs 152.7 us, K = 768 54.0 vs 53.8 us -- since the
+    // 320-row kernel no longer spills inside its K loop; ViT-L at bs = 64 gives 160 such tiles on 256 CUs and stays on the ring)
+    const long tiles5 = (long)((M + 319) / 320) * (N / 256 > 0 ? N / 256 : 1);
+    const bool one_full_round5 = shape_ok && tiles5 <= g_num_cu && tiles5 * 100 >= (long)g_num_cu * 85;
+    const bool auto_ring = nt_variant == 3 && mode == EPI_RESID && ring_ok && N <= 1024 && M >= 160 * 8 && !one_full_round5;
     if (((nt_variant == 6 || nt_variant == 7) && ring_ok) || auto_ring) {
         const int rmt = nt_variant == 6 ? 8 : 10;
         const int rgrid = ((M + 16 * rmt - 1) / (16 * rmt)) * (N / R_BN);
