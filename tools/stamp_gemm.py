@@ -40,6 +40,15 @@ if __name__ == "__main__":
     buf = (C.c_ulonglong * (4096 * 8))()
     assert L.uvit_debug_gemm_stamps(buf) == 0
     t = np.array(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
+    ph = t[3500:3500 + 32].reshape(-1)[:4 * 2 * 32].reshape(4, 2, 32)
+    if ph[0, 0, 0]:
+        names = {0: "p0 start", 1: "p0 reads+DMA issued", 2: "p0 vmcnt wait done", 3: "p0 barrier 1", 4: "p0 lds wait", 5: "p0 MMA issued",
+                 6: "p1 start (barrier 2)", 7: "p1 reads+DMA issued", 8: "p1 vmcnt wait done", 9: "p1 barrier 1", 10: "p1 lds wait", 11: "p1 MMA issued",
+                 12: "p2 start (barrier 2)", 13: "p2 reads+DMA issued", 15: "p2 barrier 1", 16: "p2 lds wait", 17: "p2 MMA issued",
+                 18: "p3 start (barrier 2)", 19: "p3 DMA issued", 20: "p3 vmcnt wait done", 21: "p3 barrier 1", 23: "p3 MMA issued", 24: "p3 barrier 2"}
+        print("K-tile 5 of the first tile, cycles since the K-tile's start; columns: workgroup 0..3 x wave group 0 / 1")
+        for k in sorted(names):
+            print(f"  {names[k]:24s} " + " ".join(f"{ph[w, gq, k] - ph[w, 0, 0]:6d}" for w in range(4) for gq in range(2)))
     if variant < 100:
         # persistent form: per workgroup, tiles 0..7: [1] K loop start, [2] K loop end, [4] next tile's operands landed, [3] epilogue end
         tp = t[2048:].reshape(256, 8, 8)

@@ -463,10 +463,20 @@ __device__ unsigned long long g_gemm_stamps[4096 * 8];
 extern "C" int uvit_debug_gemm_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)) == hipSuccess ? 0 : -3;
 }
+// one K-tile of the workgroup's first tile, phase by phase: s_memtime WITHOUT a wait (the value lands in the SGPR pair behind
+// the kernel's own lgkmcnt waits; it is only read after the K loop), so the phases are not perturbed by a drain
+#define PSTAMP_DECL unsigned long long ps_[26]; for (int k_ = 0; k_ < 26; ++k_) ps_[k_] = 0
+#define PSTAMP(k) do { if (t == 5 && first) asm volatile("s_memtime %0" : "=s"(ps_[k]) :: "memory"); } while (0)
+#define PSTAMP_FLUSH() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 4) for (int k_ = 0; k_ < 26; ++k_) \
+            g_gemm_stamps[3500 * 8 + ((blockIdx.x * 2 + (wave >> 2)) * 32 + k_)] = ps_[k_]; } while (0)
 #else
 #define GSTAMP(i)
 #define GSTAMP_P(seq, i)
 #define GSTAMP_ID()
+#define PSTAMP_DECL
+#define PSTAMP(k)
+#define PSTAMP_FLUSH()
 #endif
 
 // PERSIST (MT = 4 only): one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... and the operand pipeline runs ACROSS tiles:
@@ -621,6 +631,7 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     issue(0, 1); issue(2, 1);
     if (nk >= 2) WAIT_FULL(); else WAIT_AB();          // AL0, BL0 landed (younger: BH0 AH0 [AL1 BL1])
     bool first = true;                                 // later tiles: everything the prologue loads has already landed
+    PSTAMP_DECL;
 #ifdef GEMM_STAMP
     int seq = 0;
 #endif
@@ -647,37 +658,61 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
             const bool has1 = t + 1 < nk || more, has2 = t + 2 < nk || more;
             const bool landed = !first && t == 0;      // K-tile 0 (and AL1, BL1) of a later tile: waited for before the epilogue's stores
             // ---- phase 0: quadrant (0,0) <- AL, BL
+            PSTAMP(0);
             LOAD_B(b0f, buf + 2 * A_HALF);
             LOAD_A(buf);
             issue(3, t + 1);                           // BH(t+1): slot last read in phase 1 of tile t-1
+            PSTAMP(1);
             if (!landed) { if (has1) WAIT_FULL(); else WAIT_A(); }      // BH(t) landed (younger: AH(t) [AL BL BH](t+1))
+            PSTAMP(2);
             RAW_BARRIER();
+            PSTAMP(3);
             LDS_WAIT();
+            PSTAMP(4);
             MMA(0, 0, b0f);
+            PSTAMP(5);
             RAW_BARRIER();
             // ---- phase 1: quadrant (0,1) <- BH
+            PSTAMP(6);
             LOAD_B(b1f, buf + 2 * A_HALF + HALF_BYTES);
             issue(1, t + 1);                           // AH(t+1): slot last read in phase 2 of tile t-1
+            PSTAMP(7);
             if (!landed) { if (has1) WAIT_FULL(); else VM_WAIT(0); }    // AH(t) landed
+            PSTAMP(8);
             RAW_BARRIER();
+            PSTAMP(9);
             LDS_WAIT();
+            PSTAMP(10);
             MMA(0, 1, b1f);
+            PSTAMP(11);
             RAW_BARRIER();
             // ---- phase 2: quadrant (1,1) <- AH
+            PSTAMP(12);
             LOAD_A(buf + A_HALF);
             issue(0, t + 2);                           // AL(t+2): slot last read in phase 0
+            PSTAMP(13);
             RAW_BARRIER();
+            PSTAMP(15);
             LDS_WAIT();
+            PSTAMP(16);
             MMA(1, 1, b1f);
+            PSTAMP(17);
             RAW_BARRIER();
             // ---- phase 3: quadrant (1,0), no LDS read
+            PSTAMP(18);
             issue(2, t + 2);                           // BL(t+2): slot last read in phase 0
+            PSTAMP(19);
             if (!landed) { if (has2) WAIT_FULL(); else if (has1) WAIT_AB(); }   // AL(t+1), BL(t+1) landed (younger: BH AH (t+1) [AL BL (t+2)])
+            PSTAMP(20);
             RAW_BARRIER();
+            PSTAMP(21);
             MMA(1, 0, b0f);
+            PSTAMP(23);
             RAW_BARRIER();
+            PSTAMP(24);
         }
         if (wm == 0) RAW_BARRIER();                    // matches the trailing group's last barrier
+        if (first) PSTAMP_FLUSH();
         GSTAMP(2); GSTAMP_P(seq, 2);
 
 #define ACC1(b, ct) acc[(b) / MT][(ct) >> 1][(b) % MT][(ct) & 1]
