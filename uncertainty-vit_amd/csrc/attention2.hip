@@ -16,6 +16,7 @@
 //   fwd     : images Bm, Bc (keys), V, CV;  the wave's queries in registers
 //   bwd q   : + dMean, dCov rows in registers -> dq, dcov_q, rel-pos-bias gradient slabs, delta
 //   bwd kv  : images Am, Ac (queries), dMean, dCov; the wave's keys in registers -> dk, dcov_k, dv, dcov_v
+#include <mutex>
 #include "common.h"
 #include "uvit_internal.h"
 
@@ -535,16 +536,15 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
 // ------------------------------------------------------------------------------------------
 #define FWD2_LDS (4 * IMG_BYTES + ROWS_PAD * 4)
 #define BKV2_LDS (4 * IMG_BYTES + 3 * ROWS_PAD * 4)
-static bool g_attr2 = false;
-static void init2() {
-    if (g_attr2) return;
+static std::once_flag g_attr2_once;
+static void init2_impl() {
 #define SETA(K, B) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B)
     SETA(attn2_fwd_kernel<true>, FWD2_LDS); SETA(attn2_fwd_kernel<false>, FWD2_LDS);
     SETA(attn2_bwd_q_kernel<true>, FWD2_LDS); SETA(attn2_bwd_q_kernel<false>, FWD2_LDS);
     SETA(attn2_bwd_kv_kernel<true>, BKV2_LDS); SETA(attn2_bwd_kv_kernel<false>, BKV2_LDS);
 #undef SETA
-    g_attr2 = true;
 }
+static void init2() { std::call_once(g_attr2_once, init2_impl); }
 
 int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse,
                           int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
