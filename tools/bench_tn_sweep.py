@@ -54,7 +54,7 @@ for v in (0, 1):
     us = timed(separate)
     print(f"layer wgrads, 4 launches, variant {v}: {us:7.1f} us  {flops / us / 1e6:6.0f} TF/s")
 TUNE.tn_variant = 3
-for ch in (0, 1, 2, 3, 5, 7, 10, 14):
+for ch in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14):
     TUNE.wgrad_group_chunks = ch
     us = timed(lambda: L.uvit_op_wgrad_group(probs, 4, C.byref(TUNE), S()))
     print(f"layer wgrads, grouped, chunks {ch:2d}: {us:7.1f} us  {flops / us / 1e6:6.0f} TF/s")
