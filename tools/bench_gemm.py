@@ -88,6 +88,19 @@ if __name__ == "__main__" and "bench_gemm" in sys.argv[0]:
             row.append(f"{'auto' if v == 3 else 'v%d' % v}: {us:6.1f} us {tf:5.0f} TF")
         print(f"{names[mode]:6s} N={N:5d} K={K:5d}: " + " | ".join(row))
     TUNE.nt_variant = 3
+    if "--persist" in sys.argv:
+        print("== NT: persistent workgroups (nt_persist) on / off, 256-row kernel ==")
+        TUNE.nt_variant = 1
+        for mode, N, K in ((8, 3072, 768), (2, 3072, 768), (9, 3072, 768), (6, 3072, 768), (1, 2304, 768), (0, 3072, 768), (4, 3072, 768)):
+            row = []
+            for pz in (1, 0, 1, 0):
+                TUNE.nt_persist = pz
+                us, tf = time_nt(mode, M, N, K)
+                row.append(f"persist {pz}: {us:6.1f} us {tf:5.0f} TF")
+            print(f"{names[mode]:7s} N={N:5d} K={K:5d}: " + " | ".join(row))
+        TUNE.nt_persist = 1
+        TUNE.nt_variant = 3
+        sys.exit(0)
     if "--group" in sys.argv:
         print("== NT: column tiles per row-tile group of the tile order (nt_group), 256-row kernel ==")
         TUNE.nt_variant = 1

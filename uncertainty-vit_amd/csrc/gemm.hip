@@ -1359,7 +1359,10 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W;
     // persistent form of the 256-row kernel whenever a CU would otherwise run several workgroups back to back
     const int pgrid = g_num_cu & ~7;
-    const bool persist = variant == 1 && mt == 4 && tu.nt_persist && pgrid >= 8 && grid > pgrid;
+    // (not for the epilogues that multiply by a row operand: with the persistent form's 4-KiB staging area their fp32 blocks go
+    // through one at a time and they lose 2-3 %, tools/bench_gemm.py --persist: mulaux 153 vs 149 us, dgelu 169 vs 164 us;
+    // all other epilogues gain 6-10 %)
+    const bool persist = variant == 1 && mt == 4 && tu.nt_persist && pgrid >= 8 && grid > pgrid && mode != EPI_MULAUX && mode != EPI_DGELU;
 #define L(MODE) do { if (variant == 1 && mt == 5) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 5, false>), dim3(grid), dim3(T_THREADS), T5_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else if (persist) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4, true>), dim3(pgrid), dim3(T_THREADS), TP_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
         else if (variant == 1) hipLaunchKernelGGL((gemm_nt256_kernel<MODE, 4, false>), dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, a, w, M, N, K, lda, ldw, *epi); \
