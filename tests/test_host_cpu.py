@@ -44,6 +44,23 @@ def test_library_exports_every_declared_symbol(native):
     assert native.lib().uvit_version() == 100
 
 
+def test_ctypes_struct_mirrors_follow_the_header(native):
+    """The structs that cross the C ABI by value / by pointer are mirrored field by field in native.py: a field added to
+    include/uvit.h and forgotten there shifts everything behind it.  uvit_tuning: names from the header's one-line typedef, and
+    the library's defaults read back through the mirror (host-only call)."""
+    hdr = open(os.path.join(ROOT, "include", "uvit.h")).read()
+    m = re.search(r"typedef struct uvit_tuning \{ int32_t ([a-z_, ]+); \} uvit_tuning;", hdr)
+    fields = [f.strip() for f in m.group(1).split(",")]
+    assert [n for n, _ in native.Tuning._fields_] == fields
+    assert C.sizeof(native.Tuning) == 4 * len(fields)
+    t = native.Tuning.default()
+    assert (t.nt_variant, t.tn_variant, t.tn_split_target, t.nt_persist) == (3, 3, 512, 1)
+    body = hdr[hdr.index("typedef struct uvit_step_params"):hdr.index("} uvit_step_params;")]
+    names = re.findall(r"\b([a-z_0-9]+)(?:\[[A-Z_0-9]+\])?\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    mirror = [n for n, _ in native.StepParams._fields_]
+    assert [n for n in names if n in mirror] == mirror, (names, mirror)
+
+
 def test_arena_layout_matches_reference_state_dict(native):
     L = native.lib()
     cfg = native.Config(224, 16, 3, 768, 12, 12, 3072, 1, 0, 128, 1e-6, 0.05, 0.25, 0)
