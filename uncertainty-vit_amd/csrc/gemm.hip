@@ -529,33 +529,40 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         const int tm = bid / gw, tn = tn0 + (bid - tm * gw);
         m0_ = tm * BM_; n0_ = tn * T_BN;
     };
-    // 32-bit element offsets from the (scalar) base pointers keep the loader at LA + LA + 2 + 2 VGPRs per tile
-    struct TileSrc { uint32_t a[2][LA], b[2][2]; };    // [AL, AH][instruction], [BL, BH][instruction]
+    // Operand addressing: every LDS-DMA piece of a tile is ONE per-lane base offset (A: row m0 + 8 wave + srow, B: output
+    // column n0 + 64 (wave / 4) + 8 (wave % 4) + srow) plus a wave-uniform row step times the leading dimension, so the loader
+    // holds 2 VGPRs per tile and a piece costs one v_add in the K loop.  (Round 2 measured what the alternatives cost: ten
+    // offset VGPRs spilled inside the 320-row kernel's K loop, and recomputing row * lda per piece put ~110 issue cycles on
+    // every piece of its load blocks, profiles/round2_gemm_phase_timeline_320.txt.)  Only the ragged last row tile clamps rows
+    // per lane.
+    //   A piece j of half `kind`: tile row kind * AH_ROWS + 64 j + 8 wave + srow; in the 320-row tile the third piece of waves
+    //   4..7 is slot padding (rows 160..191 of a 160-row half) and re-reads rows 128..159.
+    //   B piece j of half `kind`: W row n0 + cb, cb = 64 (r / 32) + r % 32 (+ 32 for BH), r = 64 j + 8 wave + srow -- a wave's
+    //   2 x 32 output columns are adjacent, which gives full 128-B lines per row in the staged epilogue.
+    // The 256-row tile has the registers to keep one offset per piece (no in-loop address arithmetic at all: measured 2-3 %
+    // faster there than base + step); the 320-row tile, at the 256-VGPR limit, uses base + step.
+    struct TileSrc { uint32_t a, b; int m0; bool edge; uint32_t pa[2][LA], pb[2][2]; };
     auto tile_src = [&](int m0_, int n0_, TileSrc& ts) {
+        ts.a = (uint32_t)(m0_ + wave * 8 + srow) * (uint32_t)lda + schunk * 8;
+        ts.b = (uint32_t)(n0_ + (wave >> 2) * 64 + (wave & 3) * 8 + srow) * (uint32_t)ldw + schunk * 8;
+        ts.m0 = m0_;
+        ts.edge = m0_ + BM_ > M;
+        if constexpr (MT != 5) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            int r = (j * 8 + wave) * 8 + srow;         // row inside the half-tile slot (rows >= AH_ROWS are padding)
-            r = r < AH_ROWS ? r : AH_ROWS - 1;
-            int ra = m0_ + r;            ra = ra < M ? ra : M - 1;
-            int rb = m0_ + AH_ROWS + r;  rb = rb < M ? rb : M - 1;
-            ts.a[0][j] = (uint32_t)ra * (uint32_t)lda + schunk * 8;
-            ts.a[1][j] = (uint32_t)rb * (uint32_t)lda + schunk * 8;
-        }
+            for (int kind = 0; kind < 2; ++kind)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (j * 8 + wave) * 8 + srow;
-            // a wave's 2 x 32 output columns are adjacent (BL row r <-> column 64 (r / 32) + r % 32, BH +32): full
-            // 128-B lines per row in the staged epilogue
-            const int cb = (r >> 5) * 64 + (r & 31);
-            ts.b[0][j] = (uint32_t)(n0_ + cb) * (uint32_t)ldw + schunk * 8;
-            ts.b[1][j] = (uint32_t)(n0_ + cb + 32) * (uint32_t)ldw + schunk * 8;
+                for (int j = 0; j < LA; ++j) {
+                    int r = m0_ + kind * AH_ROWS + j * 64 + wave * 8 + srow; r = r < M ? r : M - 1;
+                    ts.pa[kind][j] = (uint32_t)r * (uint32_t)lda + schunk * 8;
+                    if (j < 2) ts.pb[kind][j] = ts.b + (uint32_t)(j * 128 + kind * 32) * (uint32_t)ldw;
+                }
         }
     };
     int vb = blockIdx.x;
     int m0, n0;
     tile_origin(vb, m0, n0);
     TileSrc cur, nxt;
-    if constexpr (MT != 5) tile_src(m0, n0, cur);
+    tile_src(m0, n0, cur);
     nxt = cur;
     const int nk = K / BK;
     int par = 0;                                       // LDS buffer of the current tile's K-tile 0 (alternates when nk is odd)
@@ -565,23 +572,17 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         if (own || more) {
             char* buf = smem + ((t + par) & 1) * BUF;
             const uint32_t k0 = (uint32_t)(own ? t : t - nk) * BK;
+            const TileSrc& T = own ? cur : nxt;
             if (kind < 2) {
                 char* dst = buf + kind * A_HALF + wave * 1024;
 #pragma unroll
                 for (int j = 0; j < LA; ++j) {
+                    int roff = kind * AH_ROWS + j * 64;
+                    if (MT == 5 && j == 2 && wave >= 4) roff -= 32;
                     uint32_t off;
-                    if constexpr (MT == 5) {
-                        // the 320-row tile sits at the 256-register limit: its operand offsets are recomputed per DMA instruction
-                        // (the VALU is idle in the K loop) instead of living in 10 VGPRs, which spilled inside the loop
-                        int sr = srow;
-                        asm volatile("" : "+v"(sr));       // opaque: keeps the recomputation inside the loop (no hoisting back into registers)
-                        int r = (j * 8 + wave) * 8 + sr;
-                        r = r < AH_ROWS ? r : AH_ROWS - 1;
-                        int ra = m0 + kind * AH_ROWS + r;  ra = ra < M ? ra : M - 1;
-                        off = (uint32_t)ra * (uint32_t)lda + schunk * 8;
-                    } else {
-                        off = own ? cur.a[kind][j] : nxt.a[kind][j];
-                    }
+                    if constexpr (MT != 5) off = T.pa[kind][j];
+                    else if (!T.edge) off = T.a + (uint32_t)roff * (uint32_t)lda;
+                    else { int r = T.m0 + roff + wave * 8 + srow; r = r < M ? r : M - 1; off = (uint32_t)r * (uint32_t)lda + schunk * 8; }
                     glds16(A + (off + k0), dst + j * 8 * 1024);
                 }
             } else {
@@ -589,15 +590,8 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     uint32_t off;
-                    if constexpr (MT == 5) {
-                        int sr = srow;
-                        asm volatile("" : "+v"(sr));
-                        const int r = (j * 8 + wave) * 8 + sr;
-                        const int cb = (r >> 5) * 64 + (r & 31) + (kind - 2) * 32;
-                        off = (uint32_t)(n0 + cb) * (uint32_t)ldw + schunk * 8;
-                    } else {
-                        off = own ? cur.b[kind - 2][j] : nxt.b[kind - 2][j];
-                    }
+                    if constexpr (MT != 5) off = T.pb[kind - 2][j];
+                    else off = T.b + (uint32_t)(j * 128 + (kind - 2) * 32) * (uint32_t)ldw;
                     glds16(W + (off + k0), dst + j * 8 * 1024);
                 }
             }
