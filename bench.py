@@ -176,7 +176,10 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_channels = None
     if world > 1:
+        from uncertainty_vit_amd.utils import cap_rccl_channels
+        rccl_channels = cap_rccl_channels()      # RCCL channel workgroups hold CUs the one-round backward kernels count on
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)     # nccl = RCCL on ROCm
 
     from uncertainty_vit_amd import optim_factory, utils
@@ -297,6 +300,7 @@ def main():
                              "frac": round(flops / (alone_ms * 1e-3) / PEAK_BF16, 4),
                              "measured": "3 single-stream steps right after the timed region (kernel alone on the GPU)"}},
             "rccl_ranks": world,
+            "rccl_max_channels": rccl_channels,
             "input_staging": staging,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -298,6 +298,16 @@ def test_bench_self_launch_command_and_clean_failure_without_gpus():
         assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
 
 
+def test_rccl_channel_cap_is_a_default_not_an_override(monkeypatch):
+    """utils.cap_rccl_channels: NCCL_MAX_NCHANNELS defaults to 8 (each channel workgroup holds a CU the one-round backward
+    kernels count on) but a value the user exported wins."""
+    from uncertainty_vit_amd import utils
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    assert utils.cap_rccl_channels() == "8" and os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "32")
+    assert utils.cap_rccl_channels() == "32"
+
+
 def test_target_layers_follow_python_list_indexing(native):
     """`[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): negative indices count from the last block,
     out-of-range raises IndexError, a repeated index is kept (it is averaged twice, the divisor is len(target_layers))."""

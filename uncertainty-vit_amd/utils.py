@@ -154,6 +154,19 @@ def setup_for_distributed(is_master):
     builtins.print = print_
 
 
+RCCL_MAX_CHANNELS = "8"
+
+
+def cap_rccl_channels():
+    """Every RCCL channel is a workgroup that holds a CU for the length of a collective.  Several backward kernels are sized to
+    fill the 256 CUs in ONE round (320-row dgrads: 237 workgroups, attention backward: 240, grouped wgrad: 216 items), and with
+    CUs taken away they need a second, nearly empty round: a run with 240 of 256 CUs (ROC_GLOBAL_CU_MASK) is 18 % slower.
+    The gradient buckets need 329 MB per ~10 ms of backward (31 GB/s algorithmic), far below what 8 channels move over xGMI,
+    so the channel count is capped unless the user has set it.  Must run before the process group is created."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", RCCL_MAX_CHANNELS)
+    return os.environ["NCCL_MAX_NCHANNELS"]
+
+
 def init_distributed_mode(args):
     """One process per GPU from RANK / WORLD_SIZE / LOCAL_RANK (utils.py:262-312). On ROCm the
     'nccl' backend is RCCL over xGMI."""
@@ -170,6 +183,8 @@ def init_distributed_mode(args):
     if use_gpu:
         torch.cuda.set_device(args.gpu)
     args.dist_backend = "nccl" if use_gpu else "gloo"
+    if use_gpu:
+        cap_rccl_channels()
     print(f"| distributed init (rank {args.rank}): {args.dist_url}, gpu {args.gpu}", flush=True)
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank)
     dist.barrier()
