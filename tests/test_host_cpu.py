@@ -299,11 +299,11 @@ def test_bench_self_launch_command_and_clean_failure_without_gpus():
 
 
 def test_rccl_channel_cap_is_a_default_not_an_override(monkeypatch):
-    """utils.cap_rccl_channels: NCCL_MAX_NCHANNELS defaults to 8 (each channel workgroup holds a CU the one-round backward
+    """utils.cap_rccl_channels: NCCL_MAX_NCHANNELS defaults to 12 (each channel workgroup holds a CU the one-round backward
     kernels count on) but a value the user exported wins."""
     from uncertainty_vit_amd import utils
     monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
-    assert utils.cap_rccl_channels() == "8" and os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    assert utils.cap_rccl_channels() == "12" and os.environ["NCCL_MAX_NCHANNELS"] == "12"
     monkeypatch.setenv("NCCL_MAX_NCHANNELS", "32")
     assert utils.cap_rccl_channels() == "32"
 

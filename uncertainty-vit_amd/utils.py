@@ -154,14 +154,14 @@ def setup_for_distributed(is_master):
     builtins.print = print_
 
 
-RCCL_MAX_CHANNELS = "8"
+RCCL_MAX_CHANNELS = "12"
 
 
 def cap_rccl_channels():
     """Every RCCL channel is a workgroup that holds a CU for the length of a collective.  Several backward kernels are sized to
     fill the 256 CUs in ONE round (320-row dgrads: 237 workgroups, attention backward: 240, grouped wgrad: 216 items), and with
     CUs taken away they need a second, nearly empty round: a run with 240 of 256 CUs (ROC_GLOBAL_CU_MASK) is 18 % slower.
-    The gradient buckets need 329 MB per ~10 ms of backward (31 GB/s algorithmic), far below what 8 channels move over xGMI,
+    The gradient buckets need 329 MB per ~10 ms of backward (31 GB/s algorithmic), far below what 12 channels move over xGMI (and 256 - 12 = 244 CUs still hold every one-round kernel),
     so the channel count is capped unless the user has set it.  Must run before the process group is created."""
     os.environ.setdefault("NCCL_MAX_NCHANNELS", RCCL_MAX_CHANNELS)
     return os.environ["NCCL_MAX_NCHANNELS"]
