@@ -503,13 +503,6 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
     constexpr int A_HALF = LA * 8 * 1024;              // its LDS slot
     constexpr int BUF = 2 * A_HALF + 2 * HALF_BYTES;   // one K-tile buffer: [AL | AH | BL | BH]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef GEMM_DESYNC
-    // experiment: a third of the first-round workgroups start half a tile period late (those CUs end up with one tile fewer)
-    if (blockIdx.x < 256 && (blockIdx.x >> 3) % 3 == GEMM_DESYNC_SET) {
-        const long long t0 = __builtin_amdgcn_s_memtime(), d = (long long)GEMM_DESYNC * (K / BK);
-        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
     GSTAMP(0); GSTAMP_ID();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
