@@ -141,6 +141,15 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_participation(dev):
+    """What RCCL itself reports: the size of the process group and the sum of one `1` per rank through an all-reduce on the
+    GPU -- proof that N ranks took part in a collective, not an echo of WORLD_SIZE."""
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "allreduce_ones": int(ones.item())}
+
+
 def launch_command(n, port, argv):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
@@ -181,6 +190,7 @@ def main():
         from uncertainty_vit_amd.utils import cap_rccl_channels
         rccl_channels = cap_rccl_channels()      # RCCL channel workgroups hold CUs the one-round backward kernels count on
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)     # nccl = RCCL on ROCm
+    rccl = rccl_participation(dev) if world > 1 else None
 
     from uncertainty_vit_amd import optim_factory, utils
     from uncertainty_vit_amd.engine_for_cyclical import GradReducer, make_step_params, native_step
@@ -299,7 +309,8 @@ def main():
                              "avg_launch_ms": round(alone_ms, 4), "achieved": round(flops / (alone_ms * 1e-3) / 1e12, 2),
                              "frac": round(flops / (alone_ms * 1e-3) / PEAK_BF16, 4),
                              "measured": "3 single-stream steps right after the timed region (kernel alone on the GPU)"}},
-            "rccl_ranks": world,
+            "rccl_ranks": rccl["allreduce_ones"] if rccl else 1,      # sum of one `1` per rank through an RCCL all-reduce
+            "rccl": rccl,
             "rccl_max_channels": rccl_channels,
             "input_staging": staging,
         }

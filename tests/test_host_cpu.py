@@ -298,6 +298,48 @@ def test_bench_self_launch_command_and_clean_failure_without_gpus():
         assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
 
 
+def test_reducer_waits_for_the_collective_on_the_stream_that_consumes_it(monkeypatch):
+    """Over RCCL Work.wait() only makes the CURRENT stream wait for the collective.  GradReducer.finish() enqueues the widening
+    copy of a bf16 bucket on its communication stream, so the wait must be issued with THAT stream current (with the
+    compute stream current the copy could read the wire buffer before RCCL had written it; gloo blocks the host and cannot see
+    it).  Fake stream / work objects record which stream each wait and copy was issued on; the old ordering fails here."""
+    from uncertainty_vit_amd.engine_for_cyclical import GradReducer
+    state = {"current": "compute"}
+    log = []
+
+    class FakeStream:
+        def __init__(self, name): self.name = name
+        def wait_stream(self, other): log.append(("join", self.name, other.name))
+
+    class FakeCtx:
+        def __init__(self, st): self.st = st
+        def __enter__(self): self.prev = state["current"]; state["current"] = self.st.name
+        def __exit__(self, *a): state["current"] = self.prev
+
+    class FakeWork:
+        def __init__(self, i): self.i, self.waited_on = i, set()
+        def wait(self): self.waited_on.add(state["current"]); log.append(("wait", self.i, state["current"]))
+
+    class FakeView:
+        def __init__(self, work): self.work = work
+        def copy_(self, wire):
+            # the stream the copy is enqueued on must already be waiting for the collective that fills `wire`
+            assert state["current"] in self.work.waited_on, f"copy on '{state['current']}' but the collective was only awaited on {self.work.waited_on}"
+            log.append(("copy", self.work.i, state["current"]))
+
+    monkeypatch.setattr(torch.cuda, "stream", lambda st: FakeCtx(st))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: FakeStream(state["current"]))
+    red = GradReducer.__new__(GradReducer)
+    red.enabled, red.on_gpu, red.comm, red.comm_dtype = True, True, FakeStream("comm"), torch.bfloat16
+    works = [FakeWork(i) for i in range(3)]
+    red.pending = [(works[0], object(), FakeView(works[0])), (works[1], None, None), (works[2], object(), FakeView(works[2]))]
+    red.finish()
+    assert red.pending == []
+    assert [e for e in log if e[0] == "wait"] == [("wait", 0, "comm"), ("wait", 1, "comm"), ("wait", 2, "comm")]
+    assert [e for e in log if e[0] == "copy"] == [("copy", 0, "comm"), ("copy", 2, "comm")]
+    assert log[-1] == ("join", "compute", "comm") and state["current"] == "compute"      # AdamW (compute stream) runs behind every bucket
+
+
 def test_rccl_channel_cap_is_a_default_not_an_override(monkeypatch):
     """utils.cap_rccl_channels: NCCL_MAX_NCHANNELS defaults to 12 (each channel workgroup holds a CU the one-round backward
     kernels count on) but a value the user exported wins."""

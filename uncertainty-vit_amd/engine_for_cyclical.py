@@ -78,13 +78,20 @@ class GradReducer:
     def finish(self):
         if not self.enabled:
             return
+        # Over RCCL, Work.wait() does not block the host: it makes the stream that is CURRENT at the call wait for the
+        # collective.  The widening copy of a bf16 bucket is enqueued on the communication stream, so that is the stream that
+        # has to wait (with the compute stream current, the copy could read `wire` before RCCL had written it; gloo's wait()
+        # blocks the host and hides the difference).  The compute stream then joins the communication stream once, below.
+        # `wire` was allocated on the communication stream and stays referenced until its copy has been enqueued there.
         for w, wire, view in self.pending:
-            w.wait()
-            if wire is not None:
-                if self.on_gpu:
-                    with torch.cuda.stream(self.comm):
+            if self.on_gpu:
+                with torch.cuda.stream(self.comm):
+                    w.wait()
+                    if wire is not None:
                         view.copy_(wire)
-                else:
+            else:
+                w.wait()
+                if wire is not None:
                     view.copy_(wire)
         self.pending = []
         if self.on_gpu:
