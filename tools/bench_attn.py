@@ -46,3 +46,10 @@ if __name__ == "__main__":
                                            0.125, p, 1, 0, S())
             us = timeit(g)
             print(f"bwd  p={p} chunk={chunk}: {us:7.1f} us (dq + dkv)  {2.5 * flops_fwd * 7 / 5 / us / 1e6:6.1f} TF/s (7 products)")
+        ws = torch.empty(L.uvit_op_attn_bwd_ws_bytes(B, H, N), dtype=torch.uint8, device="cuda")
+        slab1 = torch.zeros(H, NP, NP, device="cuda")
+        for with_dbias in (True, False):
+            g = lambda: L.uvit_op_attn_bwd_fused(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab1 if with_dbias else None), 1,
+                                                 P(ws), B, H, N, NP, 0.125, p, 1, 0, S())
+            us = timeit(g)
+            print(f"bwd  p={p} fused{' + dbias reduce' if with_dbias else '               '}: {us:7.1f} us  {2.5 * flops_fwd / us / 1e6:6.1f} TF/s (5 products)")

@@ -608,6 +608,277 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// backward, FUSED (round 3): dQ, dK, dV and dS from ONE recomputation of P.
+//
+// One 13-wave workgroup per (batch, head).  Wave w owns the 16 queries 16 w .. 16 w + 15 for the whole sample ("query on the
+// lane": S^T = K.Q^T as in the forward) and the workgroup walks the keys in steps of 32.  Per step i:
+//   A_i (every wave): S^T, dP^T of its queries against the step's 2 key tiles -> P, dS in registers (fp32) ->
+//        dQ^T += K^T.dS^T straight from the accumulators (the contraction index -- the key -- is the accumulator's row index);
+//        P (dropout applied) and dS are written ONCE, as bf16, into the step buffers [208 queries][32 keys];
+//   barrier;
+//   B_i (waves 0..7, in program order beside A_{i+1}): dV^T / dK^T of the step's 32 keys = dO^T.P / Q^T.dS, contracted over ALL
+//        queries by transposed reads of the Q / dO images and of the step buffers; the 16 x 16 result tiles are written (bf16) into
+//        the K / V image rows of step i, which nobody reads any more, and leave for HBM as full 128-B rows one barrier later;
+//        waves 8..12 meanwhile stream those rows and the dS step buffer (for the bias gradient) to HBM.
+// The step buffers are double-buffered, so there is one barrier per step.  Five MFMA products and one exp per score instead of
+// the seven products and two exps of the two-kernel form, Q / K / V / dO are read once (310 MB per layer at ViT-B bs = 128 instead
+// of 660 MB), and 3.25 waves per SIMD at <= 128 VGPRs instead of 1.75 at 256: the two older kernels kept the wave's bias rows and
+// bias-gradient accumulators (2 x 52 VGPRs) in registers.  Here the bias tile comes from L2 per (query tile, key tile) and the
+// bias gradient leaves the kernel as dS (bf16, 143 MB per layer): attn_dbias_reduce_kernel sums it over the batch.  LDS float
+// atomics are no alternative: ds_add_f32 retires one lane every 3 cycles (profiles/round3_micro_lds_atomic.txt).
+//
+// LDS: K, V, Q, dO images [208 rows][128 B] (the forward's swizzle) = 104 KiB + 2 x 2 step buffers of 13 KiB = 156 KiB.
+// Step buffer: 64-B rows of eight 8-B slots (4 keys each); slot s of row q sits at s ^ f(q), f(q) = bits (q2, q3, q1): the
+// 8-B writes of a 16-lane group (16 consecutive rows, one slot) fall in 16 different bank pairs, and a transposed read's 32-lane
+// half (8 consecutive rows x 4 slots) covers all 64 banks once.
+// ------------------------------------------------------------------------------------------
+#define FB_WAVES 13
+#define FB_ROWS (NT_MAX * 16)                 // 208
+#define FB_IMG (FB_ROWS * 128)                // 26,624 B
+#define FB_SB (FB_ROWS * 64)                  // 13,312 B
+#define FB_LDS (4 * FB_IMG + 4 * FB_SB)       // 159,744 B
+#define FB_BWAVES 8                           // waves that run the B phase (one (product, d-tile) each, both key tiles of the step)
+
+__device__ __forceinline__ int sb_off(int q, int slot) {
+    const int f = (((q >> 2) & 1) << 2) | (((q >> 3) & 1) << 1) | ((q >> 1) & 1);
+    return q * 64 + ((slot ^ f) << 3);
+}
+// B operand of the B phase: element j of lane (g, i) = buf[query (j<4 ? r_lo : r_hi) + 4g + (j&3)][key 16 tt + i]
+__device__ __forceinline__ bf16x8 sb_col_frag(const char* sb, int r_lo, int r_hi, int tt, bool has_hi, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sb + sb_off(r_lo + 4 * g + q, 4 * tt + p)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sb + sb_off(r_hi + 4 * g + q, 4 * tt + p)));
+    if (!has_hi) hi = s16x4{0, 0, 0, 0};
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(FB_WAVES * 64)
+void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
+                           const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
+                           bf16* __restrict__ dqkv, bf16* __restrict__ ds_out, int H, int N, int NP, float scale,
+                           uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kimg = smem;
+    char* const vimg = smem + FB_IMG;
+    char* const qimg = smem + 2 * FB_IMG;
+    char* const doimg = smem + 3 * FB_IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int C = H * HD;
+    const size_t ld = 3 * (size_t)C;
+    const int nt = (N + 15) >> 4, nsteps = (nt + 1) >> 1;
+    const bf16* base = qkv + (size_t)b * N * ld + h * HD;
+    const bf16* dobase = d_o + (size_t)b * N * C + h * HD;
+    const bool active = wave < nt;
+    const int q = wave * 16 + li, qr = q < N ? q : N - 1;
+
+    // ---- images by LDS-DMA: row blocks of 8; K and V first (rb-interleaved), then Q and dO; blocks beyond the last tile are never read
+    for (int p = wave; p < 4 * (FB_ROWS / 8); p += FB_WAVES) {
+        int img, rb;
+        if (p < 2 * (FB_ROWS / 8)) { img = p & 1; rb = p >> 1; } else { img = 2 + (p >= 3 * (FB_ROWS / 8)); rb = p - img * (FB_ROWS / 8); }
+        if (rb * 8 >= nt * 16) continue;
+        if (img == 3) dma_rows8(doimg, rb, dobase, (size_t)C, N, lane);
+        else dma_rows8(smem + img * FB_IMG, rb, base + (img == 2 ? 0 : (size_t)(1 + img) * C), ld, N, lane);
+    }
+    // ---- this wave's queries: Q and dO fragments (B operands of S^T and dP^T), delta = rowsum(dO o O), LSE
+    bf16x8 qf[2], dof[2];
+    float dl = 0.f, lse_q = 1e30f;                    // padded query lanes: p = exp2(.. - 1e30) = 0, so they add nothing to dK / dV
+    if (active) {
+        const size_t orow = ((size_t)b * N + qr) * C + h * HD;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[kk] = *(const bf16x8*)(base + (size_t)qr * ld + kk * 32 + g * 8);
+            dof[kk] = *(const bf16x8*)(d_o + orow + kk * 32 + g * 8);
+            const bf16x8 of = *(const bf16x8*)(o_fwd + orow + kk * 32 + g * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += bf2f(dof[kk][j]) * bf2f(of[j]);
+        }
+        dl = group_sum4(dl);
+        if (q < N) {
+            lse_q = lse[(size_t)bh * N + q];
+            if (g == 0) delta[(size_t)bh * N + q] = dl;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+    const float cs = scale * LOG2E;
+    const float* brow = HAS_BIAS ? biasP + ((size_t)h * NP + (q < NP ? q : NP - 1)) * NP + 4 * g : nullptr;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B-phase job of this wave: product pj (0: dV from P and dO, 1: dK from dS and Q), d-tile dtj
+    const int pj = wave >> 2, dtj = wave & 3;
+    const int nt2 = nsteps;                              // k-steps of the B phase: 32 queries each
+
+    // rows 32 i .. 32 i + 31 of the K / V images hold dK / dV of step i once B_i is done: 8 pieces of 8 rows, as full 128-B rows
+    auto store_rows = [&](int i, int sw) {
+        for (int c = sw; c < 8; c += FB_WAVES - FB_BWAVES) {
+            const int img = c >> 2, row = 32 * i + 8 * (c & 3) + (lane >> 3), ch = lane & 7;
+            if (row < N) {
+                const uint4 v = *(const uint4*)(smem + img * FB_IMG + img_off(row, ch));
+                *(uint4*)(dqkv + ((size_t)b * N + row) * ld + (size_t)(1 + img) * C + h * HD + ch * 8) = v;
+            }
+        }
+    };
+
+    for (int i = 0; i < nsteps; ++i) {
+        char* pb = smem + 4 * FB_IMG + (i & 1) * FB_SB;
+        char* db = pb + 2 * FB_SB;
+        const int t0 = 2 * i;
+        const bool has1 = t0 + 1 < nt;
+        // ================= A_i
+        if (active) {
+            float dsv[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsv[tt][r] = 0.f;
+                const int t = t0 + tt;
+                if (tt == 0 || has1) {
+                    float bb[4];
+                    if constexpr (HAS_BIAS) {
+                        const float4 bv = *(const float4*)(brow + t * 16);
+                        bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
+                    }
+                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], sacc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vimg, t * 16 + li, kk * 4 + g), dof[kk], dp, 0, 0, 0);
+                    }
+                    bool k4[4] = {true, true, true, true};
+                    if (drop_thr) keep4(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
+                    float pdv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sacc[r] * cs + bb[r] - lse_q);
+                        const float pd = k4[r] ? p * inv_keep : 0.f;
+                        pdv[r] = pd;
+                        dsv[tt][r] = pd * dp[r] - p * dl;
+                    }
+                    const bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
+                    const bf16x4 dv = {f2bf(dsv[tt][0]), f2bf(dsv[tt][1]), f2bf(dsv[tt][2]), f2bf(dsv[tt][3])};
+                    *(bf16x4*)(pb + sb_off(q, 4 * tt + g)) = pv;
+                    *(bf16x4*)(db + sb_off(q, 4 * tt + g)) = dv;
+                }
+            }
+            const bf16x8 dsf = pack8(dsv[0], dsv[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 kf = col_frag(kimg, t0 * 16, has1 ? t0 * 16 + 16 : t0 * 16, dt * 16, lane);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ================= B_i (waves 0..7) | row / dS streaming (waves 8..12)
+        if (wave < FB_BWAVES) {
+            const char* img = pj ? qimg : doimg;
+            const char* sb = pj ? db : pb;
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            for (int ks = 0; ks < nt2; ++ks) {
+                const bool hk = 2 * ks + 1 < nt;
+                const int r_lo = 32 * ks, r_hi = hk ? r_lo + 16 : r_lo;
+                const bf16x8 a = col_frag(img, r_lo, r_hi, dtj * 16, lane);
+                const bf16x8 b0 = sb_col_frag(sb, r_lo, r_hi, 0, hk, lane);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
+                if (has1) {
+                    const bf16x8 b1 = sb_col_frag(sb, r_lo, r_hi, 1, hk, lane);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+                }
+            }
+            // acc[tt][r] = d{V,K}[key 32 i + 16 tt + li][d = 16 dtj + 4 g + r]  ->  the dead rows of the V / K image
+            char* dst = pj ? kimg : vimg;
+            const float sc = pj ? scale : 1.0f;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt == 0 || has1) {
+                    const int row = 32 * i + 16 * tt + li;
+                    const bf16x4 v = {f2bf(acc[tt][0] * sc), f2bf(acc[tt][1] * sc), f2bf(acc[tt][2] * sc), f2bf(acc[tt][3] * sc)};
+                    *(bf16x4*)(dst + img_off(row, 2 * dtj + (g >> 1)) + ((g & 1) << 3)) = v;
+                }
+            }
+        } else {
+            const int sw = wave - FB_BWAVES;
+            if (i > 0) store_rows(i - 1, sw);
+            if (ds_out) {
+                // the dS step buffer as it stands (attn_dbias_reduce_kernel undoes the slot swizzle): 1-KiB pieces of 16 rows
+                bf16* dst = ds_out + ((size_t)bh * nsteps + i) * (FB_SB / 2);
+                for (int j = sw; j < nt; j += FB_WAVES - FB_BWAVES) {
+                    const uint4 v = *(const uint4*)(db + j * 1024 + lane * 16);
+                    *(uint4*)((char*)dst + j * 1024 + lane * 16) = v;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wave >= FB_BWAVES) store_rows(nsteps - 1, wave - FB_BWAVES);
+    if (active) {
+        // dq[dt][r] = dQ[q = li][d = 16 dt + 4 g + r]: through this wave's own 16 rows of the Q image, then 16 B per lane
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 v = {f2bf(dq[dt][0] * scale), f2bf(dq[dt][1] * scale), f2bf(dq[dt][2] * scale), f2bf(dq[dt][3] * scale)};
+            *(bf16x4*)(qimg + img_off(q, 2 * dt + (g >> 1)) + ((g & 1) << 3)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = wave * 16 + (lane >> 3) + 8 * k, ch = lane & 7;
+            const uint4 v = *(const uint4*)(qimg + img_off(row, ch));
+            if (row < N) *(uint4*)(dqkv + ((size_t)b * N + row) * ld + h * HD + ch * 8) = v;
+        }
+    }
+}
+
+// Bias gradient from the dS the fused kernel streamed out: slab[h][key][q] (+)= sum_b dS_b[h][q][key].
+// ds = [B * H][nsteps][208 rows x 64 B] bf16 step-buffer images (slot swizzle of sb_off).  One thread per (head, step, row, 16-B chunk).
+__global__ __launch_bounds__(256)
+void attn_dbias_reduce_kernel(const bf16* __restrict__ ds, float* __restrict__ slab, int accumulate, int B, int H, int N, int NP) {
+    const int nt = (N + 15) >> 4, nsteps = (nt + 1) >> 1;
+    const int total = H * nsteps * FB_ROWS * 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx & 3, q = (idx >> 2) % FB_ROWS, hi = (idx >> 2) / FB_ROWS, i = hi % nsteps, h = hi / nsteps;
+    if (q >= N) return;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const char* p = (const char*)ds + ((size_t)h * nsteps + i) * FB_SB + q * 64 + c * 16;
+    const size_t bstride = (size_t)H * nsteps * FB_SB;
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) {
+        const bf16x8 v = *(const bf16x8*)(p + b * bstride);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+    }
+    const int f = (((q >> 2) & 1) << 2) | (((q >> 3) & 1) << 1) | ((q >> 1) & 1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int slot = (2 * c + e) ^ f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = 32 * i + 4 * slot + j;
+            if (key < N) {
+                float* dst = slab + ((size_t)h * NP + key) * NP + q;
+                *dst = accumulate ? *dst + acc[4 * e + j] : acc[4 * e + j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 #define FWD_WAVES 7
@@ -623,6 +894,8 @@ static void attn_init_impl() {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
 }
 static void attn_init_once() { std::call_once(g_attn_once, attn_init_impl); }
 
@@ -642,6 +915,39 @@ int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* 
     else hipLaunchKernelGGL((attn_fwd_kernel<FWD_WAVES, false>), dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
                             biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer), g_attn_ncu);
     return uvit_check_launch();
+}
+
+size_t uvit_attn_bwd_fused_ws_bytes(int B, int H, int N) {
+    const int nt = (N + 15) / 16, nsteps = (nt + 1) / 2;
+    return (size_t)B * H * nsteps * FB_SB;
+}
+
+// ds_ws: bf16 workspace of uvit_attn_bwd_fused_ws_bytes(B, H, N) bytes (needed when dbias_slab is wanted); dbias_slab is ONE
+// [H][NP][NP] slab laid out [h][key][q]
+int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+                               float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, void* ds_ws, int B, int H,
+                               int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s,
+                               hipStream_t s_reduce) {
+    int rc = attn_check(B, H, N, HD); if (rc) return rc;
+    if (NP < NT_MAX * 16 || (dbias_slab && !ds_ws)) return UVIT_ERR_ARG;
+    attn_init_once();
+    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
+    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t key = uvit_layer_key(seed, layer);
+    bf16* dsw = dbias_slab ? (bf16*)ds_ws : nullptr;
+#define FB_ARGS dim3(B * H), dim3(FB_WAVES * 64), FB_LDS, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, biasP, lse, delta, \
+        (bf16*)dqkv, dsw, H, N, NP, scale, thr, inv_keep, key
+    if (biasP) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, FB_ARGS); else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, FB_ARGS);
+#undef FB_ARGS
+    rc = uvit_check_launch(); if (rc) return rc;
+    if (dbias_slab) {
+        (void)s_reduce;
+        const int nt = (N + 15) / 16, nsteps = (nt + 1) / 2, total = H * nsteps * FB_ROWS * 4;
+        hipLaunchKernelGGL(attn_dbias_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16*)ds_ws, dbias_slab,
+                           accumulate_slab, B, H, N, NP);
+        rc = uvit_check_launch();
+    }
+    return rc;
 }
 
 int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
