@@ -634,6 +634,31 @@ void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
 // ------------------------------------------------------------------------------------------
 #define FB_WAVES 13
 #define FB_ROWS (NT_MAX * 16)                 // 208
+// Diagnostic build only (-DATTN_STAMP, tools/stamp_attn.py): s_memtime stamps of waves 0 and 8 of every workgroup; never in libuvit.so
+#ifdef ATTN_STAMP
+__device__ unsigned long long g_attn_stamps[2048 * 2 * 16 * 2];
+#define ASTAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (lane == 0 && (wave == 0 || wave == 8) && blockIdx.x < 2048) g_attn_stamps[(blockIdx.x * 2 + (wave >> 3)) * 16 + (k)] = t_; } while (0)
+// sub-stage stamps of step 3 (waves 0 and 8): second half of the buffer
+#define BSTAMP(k) do { if (i == 3) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if (lane == 0 && (wave == 0 || wave == 8) && blockIdx.x < 2048) g_attn_stamps[2048 * 32 + (blockIdx.x * 2 + (wave >> 3)) * 16 + (k)] = t_; } } while (0)
+#define ASTAMP_ID() do { if (lane == 0 && wave == 0 && blockIdx.x < 2048) \
+        g_attn_stamps[blockIdx.x * 32 + 15] = __builtin_amdgcn_s_getreg(4 | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32); } while (0)
+extern "C" int uvit_debug_attn_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : -3;
+}
+int uvit_attn_bwd_fused_launch(const void*, const void*, const void*, const float*, const float*, float*, void*, void*, int, int, int, int,
+                               int, float, float, uint32_t, uint32_t, hipStream_t);
+extern "C" int uvit_debug_attn_bwd_fused(const void* qkv, const void* o, const void* d_o, const float* biasP, const float* lse, float* delta,
+                                         void* dqkv, void* ds_ws, float* slab, int B, int H, int N, float p_drop, void* stream) {
+    (void)slab;
+    return uvit_attn_bwd_fused_launch(qkv, o, d_o, biasP, lse, delta, dqkv, ds_ws, ds_ws != nullptr, B, H, N, 208, 0.125f, p_drop, 1u, 0u, (hipStream_t)stream);
+}
+#else
+#define ASTAMP(k)
+#define BSTAMP(k)
+#define ASTAMP_ID()
+#endif
 #define FB_IMG (FB_ROWS * 128)                // 26,624 B
 #define FB_SB (FB_ROWS * 64)                  // 13,312 B
 #define FB_LDS (4 * FB_IMG + 4 * FB_SB)       // 159,744 B
@@ -654,7 +679,9 @@ __device__ __forceinline__ bf16x8 sb_col_frag(const char* sb, int r_lo, int r_hi
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool HAS_BIAS>
+// NT_C = 13: the token count is known at compile time to need all 13 query tiles (192 < N <= 208: ViT-B/16 and ViT-L/16 at 224),
+// every loop is unrolled and every wave is active; NT_C = 0: any N <= 208 (runtime tile counts).
+template <bool HAS_BIAS, int NT_C>
 __global__ __launch_bounds__(FB_WAVES * 64)
 void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                            const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
@@ -670,11 +697,13 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
-    const int nt = (N + 15) >> 4, nsteps = (nt + 1) >> 1;
+    const int nt = NT_C ? NT_C : (N + 15) >> 4;
+    const int nsteps = (nt + 1) >> 1;
     const bf16* base = qkv + (size_t)b * N * ld + h * HD;
     const bf16* dobase = d_o + (size_t)b * N * C + h * HD;
-    const bool active = wave < nt;
+    const bool active = NT_C ? true : wave < nt;
     const int q = wave * 16 + li, qr = q < N ? q : N - 1;
+    ASTAMP(0); ASTAMP_ID();
 
     // ---- images by LDS-DMA: row blocks of 8; K and V first (rb-interleaved), then Q and dO; blocks beyond the last tile are never read
     for (int p = wave; p < 4 * (FB_ROWS / 8); p += FB_WAVES) {
@@ -684,18 +713,17 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
         if (img == 3) dma_rows8(doimg, rb, dobase, (size_t)C, N, lane);
         else dma_rows8(smem + img * FB_IMG, rb, base + (img == 2 ? 0 : (size_t)(1 + img) * C), ld, N, lane);
     }
-    // ---- this wave's queries: Q and dO fragments (B operands of S^T and dP^T), delta = rowsum(dO o O), LSE
-    bf16x8 qf[2], dof[2];
+    // ---- this wave's queries: delta = rowsum(dO o O), LSE  (their Q / dO fragments -- the B operands of S^T and dP^T -- are re-read
+    //      from the images every step: 16 registers the 128-VGPR budget does not have)
     float dl = 0.f, lse_q = 1e30f;                    // padded query lanes: p = exp2(.. - 1e30) = 0, so they add nothing to dK / dV
     if (active) {
         const size_t orow = ((size_t)b * N + qr) * C + h * HD;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            qf[kk] = *(const bf16x8*)(base + (size_t)qr * ld + kk * 32 + g * 8);
-            dof[kk] = *(const bf16x8*)(d_o + orow + kk * 32 + g * 8);
+            const bf16x8 dof = *(const bf16x8*)(d_o + orow + kk * 32 + g * 8);
             const bf16x8 of = *(const bf16x8*)(o_fwd + orow + kk * 32 + g * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f(dof[kk][j]) * bf2f(of[j]);
+            for (int j = 0; j < 8; ++j) dl += bf2f(dof[j]) * bf2f(of[j]);
         }
         dl = group_sum4(dl);
         if (q < N) {
@@ -703,19 +731,151 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
             if (g == 0) delta[(size_t)bh * N + q] = dl;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
     const float cs = scale * LOG2E;
     const float* brow = HAS_BIAS ? biasP + ((size_t)h * NP + (q < NP ? q : NP - 1)) * NP + 4 * g : nullptr;
+    // the bias tiles of a step are requested one step ahead
+    float4 bnext[2];
+    auto bias_fetch = [&](int i) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * i + tt;
+            if constexpr (HAS_BIAS) {
+                bnext[tt] = (t < nt && active) ? *(const float4*)(brow + t * 16) : make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG);
+            } else {
+                const int k0 = t * 16 + 4 * g;
+                bnext[tt] = make_float4(k0 < N ? 0.f : NEG_BIG, k0 + 1 < N ? 0.f : NEG_BIG, k0 + 2 < N ? 0.f : NEG_BIG, k0 + 3 < N ? 0.f : NEG_BIG);
+            }
+        }
+    };
+    bias_fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASTAMP(1);
+    __syncthreads();
+    ASTAMP(2);
+
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // B-phase job of this wave: product pj (0: dV from P and dO, 1: dK from dS and Q), d-tile dtj
     const int pj = wave >> 2, dtj = wave & 3;
-    const int nt2 = nsteps;                              // k-steps of the B phase: 32 queries each
 
+    // ================= A_i: this wave's 16 queries against the 2 key tiles of step i
+    auto A_step = [&](int i) {
+        char* pb = smem + 4 * FB_IMG + (i & 1) * FB_SB;
+        char* db = pb + 2 * FB_SB;
+        const int t0 = 2 * i;
+        const bool has1 = t0 + 1 < nt;
+        const float4 bcur[2] = {bnext[0], bnext[1]};
+        if (i + 1 < nsteps) bias_fetch(i + 1);
+        // NO wave-uniform branch may sit between an MFMA and the first VALU read of its result: hipcc's hazard recogniser pads the
+        // MFMA -> VALU wait states along the layout (fall-through) path only, and a taken branch that skips a block lands on the
+        // consumer too early (seen here: accumulator elements 1 and 2 stale after a skipped `if`).  So the dropout draw -- the one
+        // conditional block of the step -- comes BEFORE the MFMAs.
+        BSTAMP(4);
+        bool k4[2][4] = {{true, true, true, true}, {true, true, true, true}};
+        if (drop_thr) {
+            keep4(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4[0]);
+            keep4(drop_key, rowpair, t0 * 16 + 16 + 4 * g, drop_thr, k4[1]);
+        }
+        BSTAMP(5);
+        // Staged so that at most 16 operand registers are live: K rows -> S^T, V rows -> dP^T, softmax backward, K^T columns -> dQ^T.
+        // (With every read of the step hoisted to the top the kernel spills ~55 registers at the 128-VGPR budget of 13 waves.)
+        const int row0 = t0 * 16 + li, row1 = (has1 ? t0 + 1 : t0) * 16 + li;   // no second tile: re-read the first (its p is 0)
+        f32x4 sacc[2], dp[2];
+        {
+            const bf16x8 k00 = row_frag(kimg, row0, g), k01 = row_frag(kimg, row0, 4 + g);
+            const bf16x8 k10 = row_frag(kimg, row1, g), k11 = row_frag(kimg, row1, 4 + g);
+            const bf16x8 qf0 = row_frag(qimg, q, g), qf1 = row_frag(qimg, q, 4 + g);      // B operand: this lane's query row
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            sacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k00, qf0, z, 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k10, qf0, z, 0, 0, 0);
+            sacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k01, qf1, sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k11, qf1, sacc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        BSTAMP(6);
+        {
+            const bf16x8 v00 = row_frag(vimg, row0, g), v01 = row_frag(vimg, row0, 4 + g);
+            const bf16x8 v10 = row_frag(vimg, row1, g), v11 = row_frag(vimg, row1, 4 + g);
+            const bf16x8 do0 = row_frag(doimg, q, g), do1 = row_frag(doimg, q, 4 + g);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v00, do0, z, 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v10, do0, z, 0, 0, 0);
+            dp[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v01, do1, dp[0], 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v11, do1, dp[1], 0, 0, 0);
+        }
+        BSTAMP(7);
+        float pdv[2][4], dsv[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float bb[4] = {bcur[tt].x, bcur[tt].y, bcur[tt].z, bcur[tt].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // no second tile: its bias is -1e30, so p = 0 and the tile adds nothing
+                const float p = __builtin_amdgcn_exp2f(sacc[tt][r] * cs + bb[r] - lse_q);
+                const float pd = k4[tt][r] ? p * inv_keep : 0.f;
+                pdv[tt][r] = pd;
+                dsv[tt][r] = pd * dp[tt][r] - p * dl;
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt == 0 || has1) {
+                const bf16x4 pv = {f2bf(pdv[tt][0]), f2bf(pdv[tt][1]), f2bf(pdv[tt][2]), f2bf(pdv[tt][3])};
+                const bf16x4 dv = {f2bf(dsv[tt][0]), f2bf(dsv[tt][1]), f2bf(dsv[tt][2]), f2bf(dsv[tt][3])};
+                *(bf16x4*)(pb + sb_off(q, 4 * tt + g)) = pv;
+                *(bf16x4*)(db + sb_off(q, 4 * tt + g)) = dv;
+            }
+        }
+        const bf16x8 dsf = pack8(dsv[0], dsv[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        BSTAMP(8);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 kt = col_frag(kimg, t0 * 16, has1 ? t0 * 16 + 16 : t0 * 16, dt * 16, lane);
+            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
+        }
+        BSTAMP(9);
+    };
+
+    // ================= B_i (waves 0..7): d{V,K}^T of the step's 32 keys, contracted over every query
+    auto B_step = [&](int i) {
+        const char* pb = smem + 4 * FB_IMG + (i & 1) * FB_SB;
+        const char* sb = pj ? pb + 2 * FB_SB : pb;
+        const char* img = pj ? qimg : doimg;
+        const bool has1 = 2 * i + 1 < nt;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        // both key tiles always (a step without a second tile multiplies stale but finite slots; the result is dropped): no
+        // branch between the MFMAs and the conversion of their results (see A_step)
+        auto kstep = [&](int ks) {
+            const bool hk = 2 * ks + 1 < nt;
+            const int r_lo = 32 * ks, r_hi = hk ? r_lo + 16 : r_lo;
+            const bf16x8 a = col_frag(img, r_lo, r_hi, dtj * 16, lane);
+            const bf16x8 b0 = sb_col_frag(sb, r_lo, r_hi, 0, hk, lane);
+            const bf16x8 b1 = sb_col_frag(sb, r_lo, r_hi, 1, hk, lane);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
+        };
+        if constexpr (NT_C != 0) {
+#pragma unroll
+            for (int ks = 0; ks < (NT_C + 1) / 2; ++ks) kstep(ks);
+        } else {
+            for (int ks = 0; ks < nsteps; ++ks) kstep(ks);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // the loop exit is a branch: pad the MFMA -> VALU wait states by hand
+        // acc[tt][r] = d{V,K}[key 32 i + 16 tt + li][d = 16 dtj + 4 g + r]  ->  the dead rows of the V / K image
+        char* dst = pj ? kimg : vimg;
+        const float sc = pj ? scale : 1.0f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt == 0 || has1) {
+                const int row = 32 * i + 16 * tt + li;
+                const bf16x4 v = {f2bf(acc[tt][0] * sc), f2bf(acc[tt][1] * sc), f2bf(acc[tt][2] * sc), f2bf(acc[tt][3] * sc)};
+                *(bf16x4*)(dst + img_off(row, 2 * dtj + (g >> 1)) + ((g & 1) << 3)) = v;
+            }
+        }
+    };
     // rows 32 i .. 32 i + 31 of the K / V images hold dK / dV of step i once B_i is done: 8 pieces of 8 rows, as full 128-B rows
     auto store_rows = [&](int i, int sw) {
         for (int c = sw; c < 8; c += FB_WAVES - FB_BWAVES) {
@@ -726,104 +886,43 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
             }
         }
     };
-
-    for (int i = 0; i < nsteps; ++i) {
-        char* pb = smem + 4 * FB_IMG + (i & 1) * FB_SB;
-        char* db = pb + 2 * FB_SB;
-        const int t0 = 2 * i;
-        const bool has1 = t0 + 1 < nt;
-        // ================= A_i
-        if (active) {
-            float dsv[2][4];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dsv[tt][r] = 0.f;
-                const int t = t0 + tt;
-                if (tt == 0 || has1) {
-                    float bb[4];
-                    if constexpr (HAS_BIAS) {
-                        const float4 bv = *(const float4*)(brow + t * 16);
-                        bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
-                    }
-                    f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], sacc, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vimg, t * 16 + li, kk * 4 + g), dof[kk], dp, 0, 0, 0);
-                    }
-                    bool k4[4] = {true, true, true, true};
-                    if (drop_thr) keep4(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
-                    float pdv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(sacc[r] * cs + bb[r] - lse_q);
-                        const float pd = k4[r] ? p * inv_keep : 0.f;
-                        pdv[r] = pd;
-                        dsv[tt][r] = pd * dp[r] - p * dl;
-                    }
-                    const bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
-                    const bf16x4 dv = {f2bf(dsv[tt][0]), f2bf(dsv[tt][1]), f2bf(dsv[tt][2]), f2bf(dsv[tt][3])};
-                    *(bf16x4*)(pb + sb_off(q, 4 * tt + g)) = pv;
-                    *(bf16x4*)(db + sb_off(q, 4 * tt + g)) = dv;
-                }
-            }
-            const bf16x8 dsf = pack8(dsv[0], dsv[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 kf = col_frag(kimg, t0 * 16, has1 ? t0 * 16 + 16 : t0 * 16, dt * 16, lane);
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
-            }
+    // the dS step buffer as it stands (attn_dbias_reduce_kernel undoes the slot swizzle): 1-KiB pieces of 16 rows
+    auto stream_ds = [&](int i, int sw) {
+        if (!ds_out) return;
+        const char* db = smem + 4 * FB_IMG + (i & 1) * FB_SB + 2 * FB_SB;
+        char* dst = (char*)(ds_out + ((size_t)bh * nsteps + i) * (FB_SB / 2));
+        for (int j = sw; j < nt; j += FB_WAVES - FB_BWAVES) {
+            const uint4 v = *(const uint4*)(db + j * 1024 + lane * 16);
+            *(uint4*)(dst + j * 1024 + lane * 16) = v;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // ================= B_i (waves 0..7) | row / dS streaming (waves 8..12)
-        if (wave < FB_BWAVES) {
-            const char* img = pj ? qimg : doimg;
-            const char* sb = pj ? db : pb;
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            for (int ks = 0; ks < nt2; ++ks) {
-                const bool hk = 2 * ks + 1 < nt;
-                const int r_lo = 32 * ks, r_hi = hk ? r_lo + 16 : r_lo;
-                const bf16x8 a = col_frag(img, r_lo, r_hi, dtj * 16, lane);
-                const bf16x8 b0 = sb_col_frag(sb, r_lo, r_hi, 0, hk, lane);
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[0], 0, 0, 0);
-                if (has1) {
-                    const bf16x8 b1 = sb_col_frag(sb, r_lo, r_hi, 1, hk, lane);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[1], 0, 0, 0);
-                }
+    };
+
+    // iteration i: B_{i-1} (or the streaming of step i-1 / i-2) and A_i in ONE basic block per wave role, then the step's barrier
+#pragma unroll 1
+    for (int i = 0; i <= nsteps; ++i) {
+        {
+            if (wave < FB_BWAVES) {
+                BSTAMP(1);
+                if (i > 0) B_step(i - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                BSTAMP(2);
+                if (i < nsteps && active) A_step(i);
+            } else {
+                const int sw = wave - FB_BWAVES;
+                BSTAMP(1);
+                if (i > 1) store_rows(i - 2, sw);
+                if (i > 0) stream_ds(i - 1, sw);
+                BSTAMP(2);
+                if (i < nsteps && active) A_step(i);
             }
-            // acc[tt][r] = d{V,K}[key 32 i + 16 tt + li][d = 16 dtj + 4 g + r]  ->  the dead rows of the V / K image
-            char* dst = pj ? kimg : vimg;
-            const float sc = pj ? scale : 1.0f;
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                if (tt == 0 || has1) {
-                    const int row = 32 * i + 16 * tt + li;
-                    const bf16x4 v = {f2bf(acc[tt][0] * sc), f2bf(acc[tt][1] * sc), f2bf(acc[tt][2] * sc), f2bf(acc[tt][3] * sc)};
-                    *(bf16x4*)(dst + img_off(row, 2 * dtj + (g >> 1)) + ((g & 1) << 3)) = v;
-                }
-            }
-        } else {
-            const int sw = wave - FB_BWAVES;
-            if (i > 0) store_rows(i - 1, sw);
-            if (ds_out) {
-                // the dS step buffer as it stands (attn_dbias_reduce_kernel undoes the slot swizzle): 1-KiB pieces of 16 rows
-                bf16* dst = ds_out + ((size_t)bh * nsteps + i) * (FB_SB / 2);
-                for (int j = sw; j < nt; j += FB_WAVES - FB_BWAVES) {
-                    const uint4 v = *(const uint4*)(db + j * 1024 + lane * 16);
-                    *(uint4*)((char*)dst + j * 1024 + lane * 16) = v;
-                }
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            BSTAMP(10);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            BSTAMP(11);
+            ASTAMP(3 + i);
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     if (wave >= FB_BWAVES) store_rows(nsteps - 1, wave - FB_BWAVES);
     if (active) {
         // dq[dt][r] = dQ[q = li][d = 16 dt + 4 g + r]: through this wave's own 16 rows of the Q image, then 16 B per lane
@@ -840,41 +939,48 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
             if (row < N) *(uint4*)(dqkv + ((size_t)b * N + row) * ld + h * HD + ch * 8) = v;
         }
     }
+    ASTAMP(13);
 }
 
-// Bias gradient from the dS the fused kernel streamed out: slab[h][key][q] (+)= sum_b dS_b[h][q][key].
-// ds = [B * H][nsteps][208 rows x 64 B] bf16 step-buffer images (slot swizzle of sb_off).  One thread per (head, step, row, 16-B chunk).
+// Bias gradient from the dS the fused kernel streamed out: slab[h][key][q] += sum_b dS_b[h][q][key]  (slab zeroed by the launcher
+// unless it accumulates).  ds = [B * H][nsteps][208 rows x 64 B] bf16 step-buffer images (slot swizzle of sb_off).
+// One 256-thread workgroup per (head, step, 64 queries, batch part): thread (q, 16-B chunk) streams its chunk of every sample of the
+// part (1-KiB rows of 64 B are contiguous: 4 KiB per sample and workgroup, fully coalesced), the [32 keys][64 q] partial tile is
+// turned through LDS and added with one fp32 atomic per lane, 256 contiguous bytes per wave-instruction.
+#define DBR_PARTS 4
 __global__ __launch_bounds__(256)
-void attn_dbias_reduce_kernel(const bf16* __restrict__ ds, float* __restrict__ slab, int accumulate, int B, int H, int N, int NP) {
+void attn_dbias_reduce_kernel(const bf16* __restrict__ ds, float* __restrict__ slab, int B, int H, int N, int NP) {
+    __shared__ float tile[32][65];
     const int nt = (N + 15) >> 4, nsteps = (nt + 1) >> 1;
-    const int total = H * nsteps * FB_ROWS * 4;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx & 3, q = (idx >> 2) % FB_ROWS, hi = (idx >> 2) / FB_ROWS, i = hi % nsteps, h = hi / nsteps;
-    if (q >= N) return;
+    const int qb = blockIdx.x & 3, hi = blockIdx.x >> 2, i = hi % nsteps, h = hi / nsteps;
+    const int tid = threadIdx.x, ql = tid >> 2, c = tid & 3, q = qb * 64 + ql;
+    const int per = (B + DBR_PARTS - 1) / DBR_PARTS, b0 = blockIdx.y * per, b1 = min(B, b0 + per);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const char* p = (const char*)ds + ((size_t)h * nsteps + i) * FB_SB + q * 64 + c * 16;
-    const size_t bstride = (size_t)H * nsteps * FB_SB;
+    if (q < N) {
+        const char* p = (const char*)ds + ((size_t)h * nsteps + i) * FB_SB + q * 64 + c * 16;
+        const size_t bstride = (size_t)H * nsteps * FB_SB;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) {
-        const bf16x8 v = *(const bf16x8*)(p + b * bstride);
+        for (int b = b0; b < b1; ++b) {
+            const bf16x8 v = *(const bf16x8*)(p + b * bstride);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
     }
     const int f = (((q >> 2) & 1) << 2) | (((q >> 3) & 1) << 1) | ((q >> 1) & 1);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int slot = (2 * c + e) ^ f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = 32 * i + 4 * slot + j;
-            if (key < N) {
-                float* dst = slab + ((size_t)h * NP + key) * NP + q;
-                *dst = accumulate ? *dst + acc[4 * e + j] : acc[4 * e + j];
-            }
-        }
+        for (int j = 0; j < 4; ++j) tile[4 * slot + j][ql] = acc[4 * e + j];
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6, qo = qb * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int key = 32 * i + w * 8 + k;
+        if (key < N && qo < N) atomicAdd(slab + ((size_t)h * NP + key) * NP + qo, tile[w * 8 + k][lane]);
     }
 }
 
@@ -894,8 +1000,10 @@ static void attn_init_impl() {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true, NT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false, NT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
 }
 static void attn_init_once() { std::call_once(g_attn_once, attn_init_impl); }
 
@@ -922,32 +1030,36 @@ size_t uvit_attn_bwd_fused_ws_bytes(int B, int H, int N) {
     return (size_t)B * H * nsteps * FB_SB;
 }
 
-// ds_ws: bf16 workspace of uvit_attn_bwd_fused_ws_bytes(B, H, N) bytes (needed when dbias_slab is wanted); dbias_slab is ONE
-// [H][NP][NP] slab laid out [h][key][q]
+// ds_ws: bf16 workspace of uvit_attn_bwd_fused_ws_bytes(B, H, N) bytes, written when want_ds != 0 (the bias gradient needs it)
 int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                               float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, void* ds_ws, int B, int H,
-                               int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s,
-                               hipStream_t s_reduce) {
+                               float* delta, void* dqkv, void* ds_ws, int want_ds, int B, int H, int N, int NP, float scale,
+                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
     int rc = attn_check(B, H, N, HD); if (rc) return rc;
-    if (NP < NT_MAX * 16 || (dbias_slab && !ds_ws)) return UVIT_ERR_ARG;
+    if (NP < NT_MAX * 16 || (want_ds && !ds_ws)) return UVIT_ERR_ARG;
     attn_init_once();
     const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t key = uvit_layer_key(seed, layer);
-    bf16* dsw = dbias_slab ? (bf16*)ds_ws : nullptr;
+    bf16* dsw = want_ds ? (bf16*)ds_ws : nullptr;
 #define FB_ARGS dim3(B * H), dim3(FB_WAVES * 64), FB_LDS, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, biasP, lse, delta, \
         (bf16*)dqkv, dsw, H, N, NP, scale, thr, inv_keep, key
-    if (biasP) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, FB_ARGS); else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, FB_ARGS);
-#undef FB_ARGS
-    rc = uvit_check_launch(); if (rc) return rc;
-    if (dbias_slab) {
-        (void)s_reduce;
-        const int nt = (N + 15) / 16, nsteps = (nt + 1) / 2, total = H * nsteps * FB_ROWS * 4;
-        hipLaunchKernelGGL(attn_dbias_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const bf16*)ds_ws, dbias_slab,
-                           accumulate_slab, B, H, N, NP);
-        rc = uvit_check_launch();
+    if ((N + 15) / 16 == NT_MAX) {
+        if (biasP) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, NT_MAX>), FB_ARGS); else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, NT_MAX>), FB_ARGS);
+    } else {
+        if (biasP) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, 0>), FB_ARGS); else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, 0>), FB_ARGS);
     }
-    return rc;
+#undef FB_ARGS
+    return uvit_check_launch();
+}
+
+// dbias_slab = ONE [H][NP][NP] slab laid out [h][key][q]; accumulate = 0 overwrites it (zero fill first), 1 adds
+int uvit_attn_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accumulate, int B, int H, int N, int NP, hipStream_t s) {
+    int rc = attn_check(B, H, N, HD); if (rc) return rc;
+    if (!ds_ws || !dbias_slab || NP < NT_MAX * 16) return UVIT_ERR_ARG;
+    if (!accumulate) { rc = uvit_zero_launch(dbias_slab, (size_t)H * NP * NP * sizeof(float), s); if (rc) return rc; }
+    const int nt = (N + 15) / 16, nsteps = (nt + 1) / 2;
+    hipLaunchKernelGGL(attn_dbias_reduce_kernel, dim3(H * nsteps * 4, DBR_PARTS), dim3(256), 0, s, (const bf16*)ds_ws, dbias_slab, B, H, N, NP);
+    return uvit_check_launch();
 }
 
 int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,

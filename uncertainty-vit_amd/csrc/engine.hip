@@ -150,6 +150,7 @@ struct uvit_engine {
     bf16 *normed[2], *dout[2], *dnormed[2], *dpatch[2];
     float *meanF[2], *rstdF[2], *outputs[2], *targets[2];
     float *biasP_s, *biasP_t, *slabs, *delta;
+    void* ds_ws[2] = {nullptr, nullptr};   // fused attention backward: dS of one layer (bf16), by layer parity: the batch reduction runs on the second stream
     float *dXa, *dXb;
     bf16 *dY1[2], *dY2[2], *dH[2], *dLN, *dAttn, *dqkv[2];   // [layer parity]: read by the wgrad stream while the next layer runs
     float *dp_scales, *dp_rates;
@@ -170,6 +171,7 @@ struct uvit_engine {
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_teacher = nullptr, ev_x[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_wdone[UVIT_MAX_DEPTH] = {};
+    hipEvent_t ev_ds = nullptr;             // dS of the current layer is complete (main stream -> second stream)
     // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
@@ -217,6 +219,8 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->biasP_s = b.take<float>(bias_n); e->biasP_t = b.take<float>(bias_n);
     e->slabs = b.take<float>(bias_n * e->nchunk);
     e->delta = b.take<float>((size_t)e->B * e->H * e->N);
+    if (e->S == 1 && e->cfg.use_shared_rel_pos_bias)
+        for (int k = 0; k < 2; ++k) e->ds_ws[k] = b.take<char>(uvit_attn_bwd_fused_ws_bytes(e->B, e->H, e->N));
     e->dXa = b.take<float>(Mp * C); e->dXb = b.take<float>(Mp * C);
     for (int k = 0; k < 2; ++k) {
         e->dY1[k] = b.take<bf16>(Mp * C); e->dY2[k] = b.take<bf16>(Mp * C); e->dH[k] = b.take<bf16>(Mp * Hd);
@@ -353,7 +357,7 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
         e->dual = !(env && env[0] == '1');
         bool ok = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess;
         auto mk = [&](hipEvent_t* ev) { ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
-        mk(&e->ev_fork); mk(&e->ev_teacher);
+        mk(&e->ev_fork); mk(&e->ev_teacher); mk(&e->ev_ds);
         for (int i = 0; i < 4; ++i) mk(&e->ev_x[i]);
         for (int i = 0; i < cfg->depth; ++i) mk(&e->ev_wdone[i]);
         if (!ok) { uvit_engine_destroy(e); return fail(UVIT_ERR_LAUNCH); }
@@ -368,6 +372,7 @@ extern "C" void uvit_engine_destroy(uvit_engine* e) {
     if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_teacher) (void)hipEventDestroy(e->ev_teacher);
+    if (e->ev_ds) (void)hipEventDestroy(e->ev_ds);
     for (int i = 0; i < 4; ++i) if (e->ev_x[i]) (void)hipEventDestroy(e->ev_x[i]);
     for (int i = 0; i < UVIT_MAX_DEPTH; ++i) if (e->ev_wdone[i]) (void)hipEventDestroy(e->ev_wdone[i]);
     delete e;
@@ -784,8 +789,16 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     const float* biasP = e->biasP_s;
     float* slabs = e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr;
     if (S == 1) {
-        CHECK(uvit_attn_bwd_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, slabs, e->slab_started ? 1 : 0, e->chunk,
-                                   e->B, e->H, e->N, e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+        // fused backward: dQ, dK, dV from one recomputation of P; dS (bf16) goes to the parity buffer and its batch reduction into
+        // the ONE bias-gradient slab runs on the second stream, beside the dgrad chain.  The parity buffer of layer l was last read
+        // by the reduction of layer l + 2, which precedes ev_wdone[l + 2] on that stream (waited for above).
+        void* dsw = slabs ? e->ds_ws[par] : nullptr;
+        CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP,
+                                         0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+        if (dsw) {
+            if (e->dual) { HIPCHECK(hipEventRecord(e->ev_ds, s)); HIPCHECK(hipStreamWaitEvent(ws, e->ev_ds, 0)); }
+            CHECK(uvit_attn_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
+        }
     } else {
         CHECK(uvit_attn2_bwd_launch(a.qkv, a.qkv + Mp * 3 * C, a.attn, a.attn + Mp * C, e->dAttn, e->dAttn + Mp * C, biasP, a.lse,
                                     e->delta, dqkv, dqkv + Mp * 3 * C, slabs, e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N,
@@ -834,9 +847,9 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
         CHECK(GEMM_TN(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
     }
     if (e->cfg.use_abs_pos_emb) CHECK(uvit_pos_bwd_launch(e->dXa, g + lo.pos, e->B, e->N, C, s));     // d pos_embed = sum_b dX[b]
+    if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum / bias-gradient reduction has landed
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
-        CHECK(uvit_relpos_scatter_launch(e->slabs, e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
-    if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum has landed
+        CHECK(uvit_relpos_scatter_launch(e->slabs, e->S == 1 ? 1 : e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     // fold the replicated column-sum accumulators into the no-decay gradients
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
     CHECK(uvit_poison_if_nonfinite_launch(e->loss, g + lo.n_decay, e->poisoned, s));     // non-finite loss -> every rank's norm is NaN
@@ -954,7 +967,9 @@ extern "C" int uvit_op_attn_bwd_fused(const void* qkv, const void* o_fwd, const 
                                       float* delta, void* dqkv, float* slab, int acc, void* ds_ws, int B, int H, int N, int NP,
                                       float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
     if (!qkv || !o_fwd || !d_o || !lse || !delta || !dqkv || (slab && !ds_ws)) return UVIT_ERR_ARG;
-    return uvit_attn_bwd_fused_launch(qkv, o_fwd, d_o, biasP, lse, delta, dqkv, slab, acc, ds_ws, B, H, N, NP, scale, p_drop, seed, layer, S(st));
+    CHECK(uvit_attn_bwd_fused_launch(qkv, o_fwd, d_o, biasP, lse, delta, dqkv, ds_ws, slab != nullptr, B, H, N, NP, scale, p_drop, seed, layer, S(st)));
+    if (slab) CHECK(uvit_attn_dbias_reduce_launch(ds_ws, slab, acc, B, H, N, NP, S(st)));
+    return UVIT_OK;
 }
 extern "C" int uvit_op_attn2_fwd(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse, int B,
                                  int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {

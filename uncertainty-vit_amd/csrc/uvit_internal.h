@@ -67,12 +67,13 @@ int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, co
                          float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H,
                          int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
 // fused backward (one recomputation of P; dS leaves as bf16 for the bias gradient): ds_ws holds uvit_attn_bwd_fused_ws_bytes()
-// bytes and is only needed with dbias_slab, which is ONE [H][NP][NP] slab laid out [h][key][q]
+// bytes and is written when want_ds != 0; uvit_attn_dbias_reduce_launch sums it over the batch into ONE [H][NP][NP] slab laid out
+// [h][key][q] (accumulate = 0: the slab is zero-filled first).  Two launches so that the reduction can run on another stream.
 size_t uvit_attn_bwd_fused_ws_bytes(int B, int H, int N);
 int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                               float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, void* ds_ws, int B, int H,
-                               int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s,
-                               hipStream_t s_reduce = nullptr);
+                               float* delta, void* dqkv, void* ds_ws, int want_ds, int B, int H, int N, int NP, float scale,
+                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+int uvit_attn_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accumulate, int B, int H, int N, int NP, hipStream_t s);
 
 // attention2.hip (two-stream Wasserstein attention)
 int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse,
