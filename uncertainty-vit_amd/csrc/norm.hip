@@ -294,6 +294,9 @@ void target_finalize_kernel(float* __restrict__ acc, const int* __restrict__ cou
     else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
     else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
 
+// Slabs per CU.  Round 3 tried 2 (512 workgroups that could rebalance when some CUs are held by RCCL channel workgroups): the step was
+// slower with all CUs (25.4 -> 25.7 ms) AND with 240 / 224 CUs masked in (28.2 -> 28.8, 28.7 -> 29.5 ms; tools/cu_mask_bench.sh), so 1 stays.
+#define LNB_BLOCKS_PER_CU 1
 static int lnb_rows(int M, int resident_blocks_per_cu) {
     // rows per workgroup so that the grid is `resident_blocks_per_cu` balanced workgroups per CU
     static int ncu = 0;
@@ -327,7 +330,7 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C)) return UVIT_ERR_SHAPE;
-    const int rpb = lnb_rows(M, 1);
+    const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH2(ln_bwd_kernel, false, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, LsNext{}, rpb);
     return uvit_check_launch();
@@ -338,7 +341,7 @@ int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, con
                           int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
     if (ln_shape_ok(M, C) || tokens <= 0) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
-    const int rpb = lnb_rows(M, 1);
+    const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
     return uvit_check_launch();
