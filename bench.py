@@ -34,7 +34,24 @@ GFLOP_BY_MODEL = {"beit_base_patch16_224": 140.698, "dist_beit_base_patch16_224"
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
 ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
-TRAFFIC_BYTES = 408_000_000     # PMC: 2 x FETCH_SIZE (90.3 MB) + WRITE_SIZE (151 MB teacher / 302 MB student launch, mean 227 MB); profiles/round2_pmc_hbm.txt
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_hbm.txt")      # written by tools/pmc_run.sh (two separate --pmc passes)
+
+
+def pmc_traffic_bytes(path=PMC_SUMMARY):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary: mean over its two instantiations (teacher
+    launch: GELU; student launch: GELU + GELU') of 2 x FETCH_SIZE + WRITE_SIZE, counters in KiB (FETCH_SIZE reads half the bytes of a wide
+    coalesced stream on gfx950: MI355X_MICROARCH.md, HBM).  None when the summary is not there."""
+    try:
+        vals = {}
+        for line in open(path):
+            for tag in ("gemm_nt256_kernel<2, 4", "gemm_nt256_kernel<8, 4"):
+                if tag in line and "mean" in line:
+                    kind = "fetch" if line.startswith("fetch") else "write"
+                    vals[(tag, kind)] = float(line.split("mean")[1].split(",")[0])
+        per = [2 * vals[(t, "fetch")] + vals[(t, "write")] for t in ("gemm_nt256_kernel<2, 4", "gemm_nt256_kernel<8, 4")]
+        return int(sum(per) / len(per) * 1024)
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
 # the reference's OWN engine_for_cyclical.train_one_epoch timed in the build container (tools/time_reference.py; the
 # reference cannot travel to the GPU box): bs=4, 8 threads, 3 timed steps -- quoted beside the port's figure
 REFERENCE_ENGINE_BUILD_CONTAINER = {"img_per_s": 2.292, "s_per_step": 1.745, "threads": 8, "batch": 4, "timed_steps": 3,
@@ -164,6 +181,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-staging", action="store_true", help="skip the two extra short regions that time H2D-fed and device-synthesised batches")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the 3 extra single-stream steps that time the dominant kernel alone (profiling runs of the two-stream schedule)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce buckets (bf16 halves the xGMI bytes; AdamW accumulates in fp32 either way)")
     ap.add_argument("--model", default="beit_base_patch16_224",
@@ -260,7 +278,7 @@ def main():
     check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
     in_ms, in_n, flops = tot.value / max(n.value, 1), n.value, fl.value
     alone_ms = None
-    if not a.single_stream:
+    if not a.single_stream and not a.no_alone:
         # the same kernel alone on the GPU: a few extra single-stream steps right after the timed region
         check(L.uvit_engine_set_streams(engine.h, 0), "set_streams")
         check(L.uvit_engine_profile(engine.h, 1, 4096), "profile on")
@@ -299,7 +317,8 @@ def main():
                        "final_loss": round(float(stats[0]), 5)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU | EPI_GELU_DG> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU; the student launch also stores gelu'(h))",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": TRAFFIC_BYTES,
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic_bytes(),
+                         "traffic_source": "profiles/round3_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_run.sh): 2 x FETCH_SIZE + WRITE_SIZE per launch",
                          "algorithmic_bytes": ALGO_BYTES, "launches_timed": in_n, "avg_launch_ms": round(in_ms, 4),
                          "flops_per_launch": flops,
                          "measured": "HIP events on the launch stream over the timed region (" +

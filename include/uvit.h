@@ -220,14 +220,12 @@ int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, const uvi
  * private layout built by uvit_op_relpos_gather: bias * log2(e), -1e30 in padded key columns; lse is in log2 units */
 int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
                      float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
-int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                     float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H, int N,
-                     int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
-/* Fused backward of the same core (round 3): dQ, dK, dV from ONE recomputation of the probabilities; the score gradients
- * leave the kernel once, as bf16, into ds_workspace (uvit_op_attn_bwd_ws_bytes(B, H, N) bytes; only needed with dbias_slab) and
- * a second kernel sums them over the batch into dbias_slab = ONE (H, NP, NP) slab laid out [h][key][q] (accumulate_slab: add). */
+/* Backward of the same core (autograd of modeling_finetune.py:152-185), fused since round 3: dQ, dK, dV from ONE recomputation of
+ * the probabilities; delta (B,H,N) = rowsum(dO o O) is an output; the score gradients leave the kernel once, as bf16, into
+ * ds_workspace (uvit_op_attn_bwd_ws_bytes(B, H, N) bytes; only needed with dbias_slab) and a second kernel sums them over the
+ * batch into dbias_slab = ONE (H, NP, NP) slab laid out [h][key][q] (accumulate_slab: add; NULL: no bias gradient). */
 int64_t uvit_op_attn_bwd_ws_bytes(int B, int H, int N);
-int uvit_op_attn_bwd_fused(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                            float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, void* ds_workspace, int B, int H,
                            int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
 /* Two-stream Wasserstein attention core (modeling_finetune_dist.py:129-162 + uncertainty_evaluations.py:276-294).

@@ -172,7 +172,8 @@ def train_step(params, ema, m, v, cfg, hp: vo.StepHParams, samples, mask, step, 
         targets, cov_targets = vo.build_targets(tm, mask, hp), vo.build_targets(tc, mask, hp)
     leaves = {k: t.detach().clone().requires_grad_(True) for k, t in params.items()}
     out, cov_out = forward(leaves, cfg, samples, mask, False, None, drop)
-    loss_cyc = vo.regression_loss(out, targets, vo.StepHParams(l1_beta=hp.l1_beta, l2_loss=hp.l2_loss))
+    # loss = loss_cyc + std_loss0 * var_w0 + loss_stochastic (engine_for_cyclical.py:130-139, 161): the variance term acts on the MEAN outputs
+    loss_cyc = vo.regression_loss(out, targets, vo.StepHParams(l1_beta=hp.l1_beta, l2_loss=hp.l2_loss, var_w0=hp.var_w0, var_margin0=hp.var_margin0))
     loss_w = wasserstein_loss(out.float(), cov_out.float(), targets, cov_targets, lam)
     loss = loss_cyc + loss_w
     if hp.loss_scale != -1:

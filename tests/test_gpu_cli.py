@@ -37,3 +37,15 @@ def test_cli_trains_checkpoints_and_resumes(tmp_path, stochastic):
     assert args.start_epoch == 2
     log = [json.loads(l) for l in open(tmp_path / "log.txt")]
     assert [l["epoch"] for l in log] == [0, 1, 2] and 0 < log[2]["train_loss"] < 10
+
+
+def test_cli_config1_plumbing_size(tmp_path):
+    """BASELINE config 1 at its stated size: beit_base_patch16_224 through run_cyclical.main, batch 4, 120 masked patches per
+    image, 2 steps (8 synthetic images, 1 epoch) -- the reference runs it on the CPU as a plumbing check; here every step is native."""
+    import run_cyclical
+    argv = ["--model", "beit_base_patch16_224", "--data_set", "SYNTHETIC", "--synthetic_len", "8", "--batch_size", "4", "--epochs", "1",
+            "--warmup_epochs", "0", "--lr", "5e-4", "--target_layers", "[6,7,8,9,10,11]", "--num_mask_patches", "120", "--num_workers", "0",
+            "--output_dir", str(tmp_path), "--clip_grad", "3.0", "--drop_path", "0.25", "--attn_drop_rate", "0.05"]
+    run_cyclical.main(run_cyclical.get_args(argv))
+    log = [json.loads(l) for l in open(tmp_path / "log.txt")]
+    assert len(log) == 1 and 0 < log[0]["train_loss"] < 10 and log[0]["train_grad_norm"] > 0

@@ -197,6 +197,47 @@ def test_two_stream_dropout_step_with_replayed_masks():
     assert any(t is not None and (t == 0).any() for row in drop.path for t in row)
 
 
+def test_two_stream_step_with_variance_term():
+    """--var_w0 with --stochastic: loss = loss_cyc + std_loss0 * var_w0 + loss_stochastic (engine_for_cyclical.py:130-139, 161); the
+    variance term acts on the mean-stream outputs.  Checked against the oracle, whose variance term is pinned by the reference fixture
+    model_flags.npz and whose two-stream step by dist_d48.npz (the combination itself has no reference fixture: the loss is their sum)."""
+    from uncertainty_vit_amd import engine_for_cyclical as eng, optim_factory, utils
+    from uncertainty_vit_amd.modeling_cyclical import DistVisionTransformerForCyclicalTraining
+    from oracle.closed_form import exact_masks
+    cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=3, num_heads=2, init_values=0.1)
+    model = DistVisionTransformerForCyclicalTraining(
+        img_size=48, patch_size=16, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.1, use_shared_rel_pos_bias=True, use_abs_pos_emb=False)
+    sd = closed_form_state(vd.param_shapes(cfg), gamma=0.1)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
+    ema = utils.ModelEmaV2(model, decay=0.9998)
+    opt = optim_factory.create_optimizer(A(), model)
+    B = 6
+    x = closed_form_images("dvar", B, 48)
+    mask = exact_masks(B, 9, 4, 17)
+    outs = {}
+    for w0 in (0.0, 2.0):
+        model.load_state_dict(sd, strict=False); ema.module.load_state_dict(sd, strict=False)
+        opt = optim_factory.create_optimizer(A(), model)
+        st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, [1, 2], [((x.cuda(), mask.cuda()), torch.zeros(1))], opt,
+                                 torch.device("cuda"), 0, utils.NativeScalerWithGradNormCount(), max_norm=3.0, l1_beta=2.0, start_steps=0,
+                                 layer_results="end", var_w0=w0, var_margin0=4.0, loss_scale=-1, target_layer_norm_last=True,
+                                 post_target_layer_norm=True, stochastic=True, lambda_pretraining=1e-2)
+        p = {k: v.clone() for k, v in sd.items()}
+        e = {k: v.clone() for k, v in sd.items()}
+        m = {k: torch.zeros_like(v) for k, v in p.items()}
+        v = {k: torch.zeros_like(t) for k, t in p.items()}
+        ref, _, _, _ = vd.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=(1, 2), var_w0=w0, var_margin0=4.0), x, mask, 1, lam=1e-2)
+        assert st["loss"] == pytest.approx(ref.loss, rel=5e-3), w0
+        assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2), w0
+        outs[w0] = (st["loss"], st["loss_var0"])
+    assert outs[2.0][0] > outs[0.0][0] + 1e-3 and outs[2.0][1] > 0 and outs[0.0][1] == 0      # the term is active (margin 4 > std) and reported
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 3 and 5 at their real shapes (VERDICT round 1, "Missing 1")
 # ------------------------------------------------------------------------------------------------

@@ -123,6 +123,15 @@ def test_vitb_step_vs_oracle():
     assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)
     grads = {n: q.grad for n, q in model.named_parameters()}
     assert_grads_close(grads, ref.grads, what="[ViT-B] ")      # EVERY tensor: max-norm and relative-L2 bound
+    # The regression targets: the product's teacher runs its GEMMs on bf16 operands (deviation 1), the reference's
+    # teacher is fp32.  Measured error of the (M, 768) targets -- post-LayerNorm values, rms 1 -- against the fp32 oracle:
+    M = int(mask.sum())
+    tgt = model._engine.ws_tensor("targets", 0, (M, cfg.embed_dim)).cpu()
+    d = (tgt - ref.targets).double()
+    rel_l2, max_abs = float(d.norm() / ref.targets.double().norm()), float(d.abs().max())
+    print(f"[ViT-B] teacher targets (bf16 GEMM operands) vs fp32 oracle: relative L2 {rel_l2:.3e}, max |diff| {max_abs:.3e} "
+          f"(target rms {float(ref.targets.double().pow(2).mean().sqrt()):.3f}, max {float(ref.targets.abs().max()):.2f})")
+    assert rel_l2 < 1e-2 and max_abs < 0.1
     esd = ema.module.state_dict()
     for n in ["blocks.4.mlp.fc1.weight", "norm.weight"]:
         # first AdamW step moves every weight by +-lr; a sign flip on a ~0 gradient is 2*lr apart

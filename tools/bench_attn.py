@@ -35,21 +35,15 @@ if __name__ == "__main__":
     d_o = torch.randn(B * N, Cd, device="cuda").to(torch.bfloat16)
     lse = torch.zeros(B, H, N, device="cuda"); delta = torch.zeros_like(lse)
     dqkv = torch.zeros_like(qkv)
-    slab = torch.zeros(32, H, NP, NP, device="cuda")
     flops_fwd = 4.0 * B * H * N * N * 64
     for p in (0.0, 0.05):
         f = lambda: L.uvit_op_attn_fwd(P(qkv), P(biasP), P(out), P(lse), B, H, N, NP, 0.125, p, 1, 0, S())
         us = timeit(f)
         print(f"fwd  p={p}: {us:7.1f} us  {flops_fwd / us / 1e6:6.1f} TF/s")
-        for chunk in (7, 13):
-            g = lambda: L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab), 1, chunk, B, H, N, NP,
-                                           0.125, p, 1, 0, S())
-            us = timeit(g)
-            print(f"bwd  p={p} chunk={chunk}: {us:7.1f} us (dq + dkv)  {2.5 * flops_fwd * 7 / 5 / us / 1e6:6.1f} TF/s (7 products)")
         ws = torch.empty(L.uvit_op_attn_bwd_ws_bytes(B, H, N), dtype=torch.uint8, device="cuda")
         slab1 = torch.zeros(H, NP, NP, device="cuda")
         for with_dbias in (True, False):
-            g = lambda: L.uvit_op_attn_bwd_fused(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab1 if with_dbias else None), 1,
+            g = lambda: L.uvit_op_attn_bwd(P(qkv), P(out), P(d_o), P(biasP), P(lse), P(delta), P(dqkv), P(slab1 if with_dbias else None), 1,
                                                  P(ws), B, H, N, NP, 0.125, p, 1, 0, S())
             us = timeit(g)
             print(f"bwd  p={p} fused{' + dbias reduce' if with_dbias else '               '}: {us:7.1f} us  {2.5 * flops_fwd / us / 1e6:6.1f} TF/s (5 products)")

@@ -14,8 +14,8 @@
 // accumulator tile is directly the next MFMA's operand (no LDS round trip for P / dS).
 //
 //   fwd     : S^T = K.Q^T  -> softmax over keys -> O^T = V^T.P^T            (+ LSE saved)
-//   bwd dQ  : S^T, dP^T = V.dO^T, dS^T -> dQ^T = K^T.dS^T ; dBias^T accumulated over a batch chunk
-//   bwd dKV : S = Q.K^T, dP = dO.V^T  -> dV^T = dO^T.(P.D), dK^T = Q^T.dS
+//   bwd     : ONE fused kernel (round 3): S^T, dP^T = V.dO^T -> P, dS -> dQ^T = K^T.dS^T from the accumulators; P, dS cross LDS once
+//             for dV^T = dO^T.P, dK^T = Q^T.dS; dS also leaves as bf16 and attn_dbias_reduce_kernel sums it over the batch
 #include <mutex>
 #include "common.h"
 #include "uvit_internal.h"
@@ -24,10 +24,6 @@
 #define NT_MAX 13            // 13 * 16 = 208 >= 197 tokens
 #define ROWS_PAD 224         // 14 * 16: k-steps pair two 16-row tiles
 #define IMG_BYTES (ROWS_PAD * 128)
-#define BWD_WAVES 7
-#ifndef DQ_OCC
-#define DQ_OCC 4
-#endif
 
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -256,354 +252,6 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
                 *(bf16x4*)(dst + dt * 16) = v;
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward, query-owned: dQ, delta, and the rel-pos-bias gradient summed over a batch chunk
-//
-// One 7-wave workgroup per CU walks the samples of its (head, batch chunk, query half).  Round 2 restructure -- the old
-// kernel sat 50-75 % of its wave cycles in s_waitcnt (profiles/round1_attention.txt):
-//   * the wave's bias rows (16 queries x 208 keys, 52 VGPRs) depend on (head, query) only: they are loaded ONCE per
-//     workgroup instead of once per sample (13 L2 round trips per sample gone; the K loop has no global load left);
-//   * K / V images are double-buffered: the next sample's images are requested (into registers) before the current
-//     sample's tile loop and written to the other LDS buffer after it, so their HBM latency hides under the MFMA / exp
-//     work; one barrier per sample;
-//   * dQ leaves through a wave-private LDS slot as full 128-B rows (16 B per lane) instead of 8-B pieces in 32-B
-//     segments (WRITE_SIZE was 2.2x the algorithmic bytes, profiles/round1_pmc_hbm_v10.txt).
-// 256-VGPR budget (2 waves per SIMD at most): bias 52 + dBias accumulators 52 + image prefetch 32 + the tile state.
-// ------------------------------------------------------------------------------------------
-#define DQ_STAGE_BYTES (16 * 128)            // one wave's 16 x 64 bf16 dQ tile
-#define DQ_LDS_BYTES (4 * IMG_BYTES + BWD_WAVES * DQ_STAGE_BYTES)
-
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(BWD_WAVES * 64, 2)
-void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
-                        const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
-                        bf16* __restrict__ dqkv, float* __restrict__ dbias_slab, int accumulate_slab,
-                        int B, int H, int N, int NP, int chunk, int nhalf, float scale, uint32_t drop_thr,
-                        float inv_keep, uint32_t drop_key) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, li = lane & 15;
-    const int half = blockIdx.x % nhalf;
-    const int hc = blockIdx.x / nhalf;
-    const int h = hc % H, c = hc / H;
-    const int C = H * HD;
-    const size_t ld = 3 * (size_t)C;
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-    const int qt = half * BWD_WAVES + wave;
-    const bool active = qt < nt;
-    const int q = qt * 16 + li;
-    const int qr = q < N ? q : N - 1;
-    char* stage = smem + 4 * IMG_BYTES + wave * DQ_STAGE_BYTES;
-    const int b0 = c * chunk, b1 = min(B, b0 + chunk);
-
-    // bias rows of this wave's queries, once per workgroup: bb[t][r] = biasP[h][q][16 t + 4 g + r]
-    float bb[NT_MAX][4];
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t) {
-        if constexpr (HAS_BIAS) {
-            const float4 bv = (t < nt && active) ? *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g)
-                                                 : make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG);
-            bb[t][0] = bv.x; bb[t][1] = bv.y; bb[t][2] = bv.z; bb[t][3] = bv.w;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bb[t][r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
-        }
-    }
-    float dbacc[NT_MAX][4];
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dbacc[t][r] = 0.f;
-
-    // image staging: 2 images x 224 rows x 8 chunks = 3584 16-B pieces, 8 per thread
-    constexpr int PF = (2 * ROWS_PAD * 8) / (BWD_WAVES * 64);
-    static_assert(PF * BWD_WAVES * 64 == 2 * ROWS_PAD * 8, "image pieces must divide evenly over the workgroup");
-    uint4 pf[PF];
-    auto fetch = [&](int b) {                      // request sample b's K and V rows
-        const bf16* base = qkv + (size_t)b * N * ld + h * HD + C;
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int idx = tid + k * BWD_WAVES * 64;
-            const int img = idx / (ROWS_PAD * 8), rem = idx - img * (ROWS_PAD * 8);
-            const int row = rem >> 3, ch = rem & 7;
-            pf[k] = row < N ? *(const uint4*)(base + (size_t)img * C + (size_t)row * ld + ch * 8) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto commit = [&](int buf) {                   // ... and place them in LDS buffer `buf`
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int idx = tid + k * BWD_WAVES * 64;
-            const int img = idx / (ROWS_PAD * 8), rem = idx - img * (ROWS_PAD * 8);
-            *(uint4*)(smem + (2 * buf + img) * IMG_BYTES + img_off(rem >> 3, rem & 7)) = pf[k];
-        }
-    };
-    if (b0 < b1) { fetch(b0); commit(0); }
-    for (int b = b0; b < b1; ++b) {
-        const int buf = (b - b0) & 1;
-        __syncthreads();                           // buffer `buf` is complete; nobody reads buffer `buf ^ 1` any more
-        const bool more = b + 1 < b1;
-        if (more) fetch(b + 1);
-        const char* kimg = smem + (2 * buf) * IMG_BYTES;
-        const char* vimg = kimg + IMG_BYTES;
-        if (active) {
-            const int bh = b * H + h;
-            const bf16* base = qkv + (size_t)b * N * ld + h * HD;
-            bf16x8 qf[2], dof[2];
-            const size_t orow = ((size_t)b * N + qr) * C + h * HD;
-            float dl = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                qf[kk] = *(const bf16x8*)(base + (size_t)qr * ld + kk * 32 + g * 8);
-                dof[kk] = *(const bf16x8*)(d_o + orow + kk * 32 + g * 8);
-                const bf16x8 of = *(const bf16x8*)(o_fwd + orow + kk * 32 + g * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dl += bf2f(dof[kk][j]) * bf2f(of[j]);
-            }
-            dl = group_sum4(dl);
-            const float lse_q = lse[(size_t)bh * N + qr];
-            if (g == 0 && q < N) delta[(size_t)bh * N + q] = dl;
-            const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
-            const float cs = scale * LOG2E;
-
-            f32x4 dq[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
-                if (ks < nt2) {
-                    float dsv[2][4];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        const int t = 2 * ks + tt;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dsv[tt][r] = 0.f;
-                        if (t < nt && t < NT_MAX) {
-                            f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int kk = 0; kk < 2; ++kk) {
-                                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(kimg, t * 16 + li, kk * 4 + g), qf[kk], sacc, 0, 0, 0);
-                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(vimg, t * 16 + li, kk * 4 + g), dof[kk], dp, 0, 0, 0);
-                            }
-                            bool k4[4] = {true, true, true, true};
-                            if (drop_thr) keep4(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                // padded keys: bias = -1e30 -> p = 0; padded query lanes are never stored / read
-                                const float p = __builtin_amdgcn_exp2f(sacc[r] * cs + bb[t < NT_MAX ? t : 0][r] - lse_q);
-                                const float dpv = k4[r] ? dp[r] * inv_keep : 0.f;
-                                const float ds = p * (dpv - dl);
-                                dsv[tt][r] = ds;
-                                dbacc[t < NT_MAX ? t : 0][r] += ds;
-                            }
-                        }
-                    }
-                    const bf16x8 dsf = pack8(dsv[0], dsv[1]);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const bf16x8 kf = col_frag(kimg, 2 * ks * 16, (2 * ks + 1) * 16, dt * 16, lane);
-                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf, dq[dt], 0, 0, 0);
-                    }
-                }
-            }
-            // dq[dt][r] = dQ[q = li][d = 16 dt + 4 g + r]: through the wave's LDS slot ([16 rows][128 B], chunk ^ row),
-            // then 16 B per lane: lane -> row (lane >> 3) + 8 i, chunk lane & 7  (one wave's LDS ops execute in order)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x4 v = {f2bf(dq[dt][0] * scale), f2bf(dq[dt][1] * scale), f2bf(dq[dt][2] * scale), f2bf(dq[dt][3] * scale)};
-                *(bf16x4*)(stage + li * 128 + (((2 * dt + (g >> 1)) ^ (li & 7)) << 4) + ((g & 1) << 3)) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (lane >> 3) + 8 * i, ch = lane & 7;
-                const uint4 v = *(const uint4*)(stage + row * 128 + ((ch ^ (row & 7)) << 4));
-                const int qq = qt * 16 + row;
-                if (qq < N) *(uint4*)(dqkv + ((size_t)b * N + qq) * ld + h * HD + ch * 8) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (more) commit(buf ^ 1);
-    }
-    if (dbias_slab && active) {
-        // slab[c][h][key][q]  (transposed: q is the contiguous index, 16 lanes -> 64 B)
-        float* slab = dbias_slab + ((size_t)(c * H + h) * NP) * NP;
-#pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + 4 * g + r;
-                    float* p = slab + (size_t)key * NP + q;
-                    *p = accumulate_slab ? *p + dbacc[t][r] : dbacc[t][r];
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward, key-owned: dK, dV.  Same shape as the dQ kernel: one 7-wave workgroup per CU walks the samples of its
-// (head, batch chunk, key half) with double-buffered Q / dO images (+ the per-query LSE and delta vectors), the wave's
-// bias COLUMNS (208 queries x 16 keys, 52 VGPRs) loaded once per workgroup, and dK / dV leaving as full 128-B rows.
-// ------------------------------------------------------------------------------------------
-#define DKV_VEC_BYTES (2 * ROWS_PAD * 4)                                   // lse + delta of one sample
-#define DKV_LDS_BYTES (4 * IMG_BYTES + 2 * DKV_VEC_BYTES + BWD_WAVES * DQ_STAGE_BYTES)
-
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(BWD_WAVES * 64, 2)
-void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ biasP,
-                         const float* __restrict__ lse, const float* __restrict__ delta, bf16* __restrict__ dqkv,
-                         int B, int H, int N, int NP, int chunk, int nhalf, float scale, uint32_t drop_thr, float inv_keep,
-                         uint32_t drop_key) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* vecs = (float*)(smem + 4 * IMG_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, li = lane & 15;
-    const int half = blockIdx.x % nhalf;
-    const int hc = blockIdx.x / nhalf;
-    const int h = hc % H, c = hc / H;
-    const int C = H * HD;
-    const size_t ld = 3 * (size_t)C;
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-    const int kt = half * BWD_WAVES + wave;
-    const bool active = kt < nt;
-    const int key = kt * 16 + li;
-    const int kr = key < N ? key : N - 1;
-    char* stage = smem + 4 * IMG_BYTES + 2 * DKV_VEC_BYTES + wave * DQ_STAGE_BYTES;
-    const int b0 = c * chunk, b1 = min(B, b0 + chunk);
-
-    // bias columns of this wave's keys, once per workgroup: bb[qt][r] = biasP[h][16 qt + 4 g + r][key]
-    float bb[NT_MAX][4];
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if constexpr (HAS_BIAS) bb[t][r] = (t < nt && active) ? biasP[((size_t)h * NP + t * 16 + 4 * g + r) * NP + key] : NEG_BIG;
-            else bb[t][r] = key < N ? 0.f : NEG_BIG;
-        }
-
-    // image staging in two halves (Q, then dO) so that only ONE image's 16 VGPRs of prefetch are live at a time: the target
-    // buffer is idle for the whole sample, so each half is committed as soon as the tile loop has covered its latency
-    constexpr int PF = (ROWS_PAD * 8) / (BWD_WAVES * 64);
-    static_assert(PF * BWD_WAVES * 64 == ROWS_PAD * 8, "image pieces must divide evenly over the workgroup");
-    uint4 pf[PF];
-    float pfv = 0.f;
-    auto fetch = [&](int b, int img) {             // request one image of sample b: img 0 = Q (+ lse / delta), 1 = dO
-        const bf16* src0 = img ? d_o + (size_t)b * N * C + h * HD : qkv + (size_t)b * N * ld + h * HD;
-        const size_t stride = img ? (size_t)C : ld;
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int idx = tid + k * BWD_WAVES * 64;
-            const int row = idx >> 3, ch = idx & 7;
-            pf[k] = row < N ? *(const uint4*)(src0 + (size_t)row * stride + ch * 8) : make_uint4(0, 0, 0, 0);
-        }
-        if (img == 0) {
-            // thread t < 224: lse[t]; 224 <= t < 448: delta[t - 224]   (zero beyond N: padded query rows contribute nothing)
-            const int i = tid < ROWS_PAD ? tid : tid - ROWS_PAD;
-            const float* v = tid < ROWS_PAD ? lse : delta;
-            pfv = i < N ? v[(size_t)(b * H + h) * N + i] : 0.f;
-        }
-    };
-    auto commit = [&](int buf, int img) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int idx = tid + k * BWD_WAVES * 64;
-            *(uint4*)(smem + (2 * buf + img) * IMG_BYTES + img_off(idx >> 3, idx & 7)) = pf[k];
-        }
-        if (img == 0) vecs[buf * 2 * ROWS_PAD + tid] = pfv;
-    };
-    static_assert(BWD_WAVES * 64 == 2 * ROWS_PAD, "one lse / delta element per thread");
-    if (b0 < b1) { fetch(b0, 0); commit(0, 0); fetch(b0, 1); commit(0, 1); }
-    const float cs = scale * LOG2E;
-    for (int b = b0; b < b1; ++b) {
-        const int buf = (b - b0) & 1;
-        __syncthreads();
-        const bool more = b + 1 < b1;
-        if (more) fetch(b + 1, 0);
-        const char* qimg = smem + (2 * buf) * IMG_BYTES;
-        const char* doimg = qimg + IMG_BYTES;
-        const float* lse_s = vecs + buf * 2 * ROWS_PAD;
-        const float* dl_s = lse_s + ROWS_PAD;
-        const int bh = b * H + h;
-        bf16x8 kf[2], vf[2];
-        if (active) {
-            const bf16* base = qkv + (size_t)b * N * ld + h * HD;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                kf[kk] = *(const bf16x8*)(base + C + (size_t)kr * ld + kk * 32 + g * 8);
-                vf[kk] = *(const bf16x8*)(base + 2 * C + (size_t)kr * ld + kk * 32 + g * 8);
-            }
-        }
-        f32x4 dk[4], dv[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int qs = 0; qs < (NT_MAX + 1) / 2; ++qs) {
-            if (qs == 3 && more) { commit(buf ^ 1, 0); fetch(b + 1, 1); }       // every thread: Q image placed, dO image requested
-            if (active && qs < nt2) {
-                float pdv[2][4], dsv[2][4];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int qt = 2 * qs + tt;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pdv[tt][r] = 0.f; dsv[tt][r] = 0.f; }
-                    if (qt < nt && qt < NT_MAX) {
-                        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(qimg, qt * 16 + li, kk * 4 + g), kf[kk], sacc, 0, 0, 0);
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(doimg, qt * 16 + li, kk * 4 + g), vf[kk], dp, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            // padded query rows have zero Q / dO / delta / lse and a zero bias row: p stays finite and its
-                            // products vanish; padded keys (bias -1e30) give p = 0
-                            const int qq = qt * 16 + 4 * g + r;
-                            const float p = __builtin_amdgcn_exp2f(sacc[r] * cs + bb[qt < NT_MAX ? qt : 0][r] - lse_s[qq]);
-                            float dmul = 1.0f;
-                            if (drop_thr) dmul = keep1(drop_key, ((uint32_t)bh * N + qq) * (uint32_t)(NP >> 1), key, drop_thr) ? inv_keep : 0.f;
-                            pdv[tt][r] = p * dmul;
-                            dsv[tt][r] = p * (dmul * dp[r] - dl_s[qq]);
-                        }
-                    }
-                }
-                const bf16x8 pdf = pack8(pdv[0], pdv[1]);
-                const bf16x8 dsf = pack8(dsv[0], dsv[1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const bf16x8 dot = col_frag(doimg, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane);
-                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdf, dv[dt], 0, 0, 0);
-                    const bf16x8 qtf = col_frag(qimg, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dk[dt], 0, 0, 0);
-                }
-            }
-        }
-        if (active) {
-            // dK then dV through the wave's LDS slot, stored as full 128-B rows (see the dQ kernel)
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const f32x4 a = which ? dv[dt] : dk[dt];
-                    const float sc = which ? 1.0f : scale;
-                    const bf16x4 v = {f2bf(a[0] * sc), f2bf(a[1] * sc), f2bf(a[2] * sc), f2bf(a[3] * sc)};
-                    *(bf16x4*)(stage + li * 128 + (((2 * dt + (g >> 1)) ^ (li & 7)) << 4) + ((g & 1) << 3)) = v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = (lane >> 3) + 8 * i, ch = lane & 7;
-                    const uint4 v = *(const uint4*)(stage + row * 128 + ((ch ^ (row & 7)) << 4));
-                    const int kk_ = kt * 16 + row;
-                    if (kk_ < N) *(uint4*)(dqkv + ((size_t)b * N + kk_) * ld + (1 + which) * C + h * HD + ch * 8) = v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        if (more) commit(buf ^ 1, 1);
     }
 }
 
@@ -996,10 +644,6 @@ static void attn_init_impl() {
         g_attn_ncu = prop.multiProcessorCount;
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<FWD_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
     (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<true, NT_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS);
@@ -1062,25 +706,3 @@ int uvit_attn_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accu
     return uvit_check_launch();
 }
 
-int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                         float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H,
-                         int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
-    int rc = attn_check(B, H, N, HD); if (rc) return rc;
-    if (chunk <= 0) return UVIT_ERR_ARG;
-    attn_init_once();
-    const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
-    const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t key = uvit_layer_key(seed, layer);
-    const int nt = (N + 15) / 16, nhalf = nt > BWD_WAVES ? 2 : 1;
-    const int nchunk = (B + chunk - 1) / chunk;
-#define DQ_ARGS dim3(H * nchunk * nhalf), dim3(BWD_WAVES * 64), DQ_LDS_BYTES, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, \
-        biasP, lse, delta, (bf16*)dqkv, dbias_slab, accumulate_slab, B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key
-    if (biasP) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, DQ_ARGS); else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, DQ_ARGS);
-#undef DQ_ARGS
-    rc = uvit_check_launch(); if (rc) return rc;
-#define DKV_ARGS dim3(H * nchunk * nhalf), dim3(BWD_WAVES * 64), DKV_LDS_BYTES, s, (const bf16*)qkv, (const bf16*)d_o, \
-        biasP, lse, delta, (bf16*)dqkv, B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key
-    if (biasP) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, DKV_ARGS); else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, DKV_ARGS);
-#undef DKV_ARGS
-    return uvit_check_launch();
-}

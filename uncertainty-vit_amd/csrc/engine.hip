@@ -953,17 +953,11 @@ extern "C" int uvit_op_attn_fwd(const void* qkv, const float* biasP, void* out, 
     if (!qkv || !out || !lse) return UVIT_ERR_ARG;
     return uvit_attn_fwd_launch(qkv, biasP, out, lse, B, H, N, NP, scale, p_drop, seed, layer, S(st));
 }
-extern "C" int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                                float* delta, void* dqkv, float* slab, int acc, int chunk, int B, int H, int N, int NP,
-                                float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
-    if (!qkv || !o_fwd || !d_o || !lse || !delta || !dqkv) return UVIT_ERR_ARG;
-    return uvit_attn_bwd_launch(qkv, o_fwd, d_o, biasP, lse, delta, dqkv, slab, acc, chunk, B, H, N, NP, scale, p_drop, seed, layer, S(st));
-}
 extern "C" int64_t uvit_op_attn_bwd_ws_bytes(int B, int H, int N) {
     if (B < 1 || H < 1 || N < 1 || N > 208) return UVIT_ERR_SHAPE;
     return (int64_t)uvit_attn_bwd_fused_ws_bytes(B, H, N);
 }
-extern "C" int uvit_op_attn_bwd_fused(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
+extern "C" int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                                       float* delta, void* dqkv, float* slab, int acc, void* ds_ws, int B, int H, int N, int NP,
                                       float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream st) {
     if (!qkv || !o_fwd || !d_o || !lse || !delta || !dqkv || (slab && !ds_ws)) return UVIT_ERR_ARG;

@@ -63,9 +63,6 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const G
 // attention.hip
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
                          float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
-int uvit_attn_bwd_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
-                         float* delta, void* dqkv, float* dbias_slab, int accumulate_slab, int chunk, int B, int H,
-                         int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
 // fused backward (one recomputation of P; dS leaves as bf16 for the bias gradient): ds_ws holds uvit_attn_bwd_fused_ws_bytes()
 // bytes and is written when want_ds != 0; uvit_attn_dbias_reduce_launch sums it over the batch into ONE [H][NP][NP] slab laid out
 // [h][key][q] (accumulate = 0: the slab is zero-filled first).  Two launches so that the reduction can run on another stream.
