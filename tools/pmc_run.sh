@@ -3,16 +3,17 @@
 # HBM bytes per launch of the main kernels: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short
 # single-stream bench run, as MI355X_MICROARCH.md prescribes (no trace domains beside --pmc; FETCH_SIZE x2 on gfx950).
 tag=${1:-pmc}
+model=${2:-beit_base_patch16_224}
 export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/${tag}
 mkdir -p $out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --single-stream > $out/$c.log 2>&1 || { echo "pmc pass $c failed"; tail -5 $out/$c.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-input-staging --single-stream --model $model > $out/$c.log 2>&1 || { echo "pmc pass $c failed"; tail -5 $out/$c.log; exit 1; }
 done
 cd $root
-for k in "gemm_nt256_kernel<2, 4" "gemm_nt256_kernel<8, 4" "gemm_nt256_kernel<9, 4" "gemm_ntr_kernel<3, 10>" "gemm_nt256_kernel<1, 4" "gemm_nt256_kernel<0, 4" "gemm_nt256_kernel<0, 5" "gemm_nt_kernel<" "gemm_tn256_group" attn_fwd attn_bwd_fused attn_dbias_reduce ln_bwd ln_fwd adamw; do
+for k in "gemm_nt256_kernel<2, 4" "gemm_nt256_kernel<8, 4" "gemm_nt256_kernel<9, 4" "gemm_ntr_kernel<3, 10>" "gemm_nt256_kernel<1, 4" "gemm_nt256_kernel<0, 4" "gemm_nt256_kernel<0, 5" "gemm_nt_kernel<" "gemm_tn256_group" attn_fwd attn_bwd_fused attn_dbias_reduce attn2_fwd attn2_bwd_q attn2_bwd_kv ln_bwd ln_fwd adamw; do
   python tools/pmc_summary.py $out/FETCH_SIZE "$k" | sed 's/^.*counter_collection.csv: /fetch: /'
   python tools/pmc_summary.py $out/WRITE_SIZE "$k" | sed 's/^.*counter_collection.csv: /write: /'
 done | tee $out/summary.txt

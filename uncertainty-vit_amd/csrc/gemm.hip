@@ -1332,8 +1332,9 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     if (variant == 1 && mt == 4 && nt_variant == 3 && mode != EPI_PATCH) {
         const int tiles_n = N / T_BN, tiles = ((M + T_BM - 1) / T_BM) * tiles_n;
         const int rounds = tiles / g_num_cu, over = tiles - rounds * g_num_cu;
-        // (round 3: up to HALF a round of overflow goes to the tail -- QKV at bs = 128: 891 tiles = 3 rounds + 123; A/B 93.2 -> 88.9 us)
-        if (rounds >= 1 && over > 0 && over * 2 <= g_num_cu) {
+        // (round 3 tried half a round of overflow -- QKV at bs = 128: 891 tiles = 3 rounds + 123: 93.2 -> 88.9 us alone, but inside the
+        //  step the 3-round launch + its 128x128 tail take the same 91.7 us as the 4-round launch: profiles/round3_gemm_pair_kernel_experiment.txt)
+        if (rounds >= 1 && over > 0 && over * 4 <= g_num_cu) {
             const int rows_a = (rounds * g_num_cu / tiles_n) * T_BM;
             if (rows_a > 0 && rows_a < M) { m_tail = M - rows_a; M = rows_a; }
         }
