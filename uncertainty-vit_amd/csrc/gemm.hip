@@ -704,6 +704,10 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 
 #define ACC1(b, ct) acc[(b) / MT][(ct) >> 1][(b) % MT][(ct) & 1]
 #define MB1(b) (m0 + ((b) / MT) * AH_ROWS + wm * 16 * MT + ((b) % MT) * 16)
+        // the trailing wave group loses the VALU arbitration in the epilogue (round-2 stamps: it finishes 2-11k cycles after the leading
+        // one, which then idles at the next tile's first barrier): it runs the epilogue at priority 1 (round 3 A/B, fc1 GELU+GELU'
+        // 158.1 -> 153.4 us, fc1 GELU 144.8 -> 140.9 us, qkv 92.8 -> 91.4 us; priority 3 is no better)
+        if (wm == 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (PERSIST) {
             // the next tile's K-tile 0 + AL1 BL1 were issued during the last two K-tiles: land them BEFORE the first store
             VM_WAIT(0);
@@ -712,6 +716,7 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         } else {
             EPI_RUN(MODE, 2 * MT, smem + wave * EPI_WAVE_BYTES, n0 + wn * 64, ACC1, MB1);
         }
+        __builtin_amdgcn_s_setprio(0);
 #undef ACC1
 #undef MB1
         GSTAMP(3); GSTAMP_P(seq, 3);
