@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-o
 # Fingerprint of the sources this library is built from: native.lib() recomputes it and refuses a stale .so
 # (struct layouts in include/uvit.h travel by value through ctypes).
 HASH=$(cat $(ls *.hip *.h | LC_ALL=C sort) ../../include/uvit.h | sha256sum | cut -c1-16)
-FLAGS="$FLAGS -DUVIT_SRC_HASH=\"$HASH\""
+FLAGS="$FLAGS -DUVIT_SRC_HASH=\"$HASH\" $UVIT_EXTRA_FLAGS"   # UVIT_EXTRA_FLAGS: -D switches of A/B experiments
 mkdir -p obj
 pids=()
 for f in gemm attention attention2 norm elementwise optim engine; do

@@ -707,6 +707,8 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         // the trailing wave group loses the VALU arbitration in the epilogue (round-2 stamps: it finishes 2-11k cycles after the leading
         // one, which then idles at the next tile's first barrier): it runs the epilogue at priority 1 (round 3 A/B, fc1 GELU+GELU'
         // 158.1 -> 153.4 us, fc1 GELU 144.8 -> 140.9 us, qkv 92.8 -> 91.4 us; priority 3 is no better)
+        // K-loop variants measured beside it and dropped: static priority for this group without the per-block flips (+15-20 %),
+        // flips with either group one level above the other (+10-15 %); profiles/round3_gemm_epilogue_priority_ab.txt
         if (wm == 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (PERSIST) {
             // the next tile's K-tile 0 + AL1 BL1 were issued during the last two K-tiles: land them BEFORE the first store
