@@ -706,7 +706,8 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #define MB1(b) (m0 + ((b) / MT) * AH_ROWS + wm * 16 * MT + ((b) % MT) * 16)
         // the trailing wave group loses the VALU arbitration in the epilogue (round-2 stamps: it finishes 2-11k cycles after the leading
         // one, which then idles at the next tile's first barrier): it runs the epilogue at priority 1 (round 3 A/B, fc1 GELU+GELU'
-        // 158.1 -> 153.4 us, fc1 GELU 144.8 -> 140.9 us, qkv 92.8 -> 91.4 us; priority 3 is no better)
+        // 158.1 -> 153.4 us, fc1 GELU 144.8 -> 140.9 us, qkv 92.8 -> 91.4 us; priority 3 is no better).  Inside the two-stream step the gain
+        // is within noise (same box, alternating: 25.31 / 25.36 / 25.41 ms with, 25.35 / 25.49 / 25.39 ms without).
         // K-loop variants measured beside it and dropped: static priority for this group without the per-block flips (+15-20 %),
         // flips with either group one level above the other (+10-15 %); profiles/round3_gemm_epilogue_priority_ab.txt
         if (wm == 1) __builtin_amdgcn_s_setprio(1);
