@@ -42,6 +42,58 @@ __global__ __launch_bounds__(WAVES * 64) void dma_kernel(const char* __restrict_
     if (lane == 0 && wave == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the same stream by BUFFER addressing: buffer_load_dwordx4 ... lds (one 32-bit offset per lane against a wave-uniform descriptor)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void bdma_kernel(const char* __restrict__ src, size_t footprint, int steps, size_t row_stride,
+                                                          unsigned long long* __restrict__ cyc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int PIECES = 64 / WAVES;
+    const uint32_t lane_off = (uint32_t)((lane >> 3) * row_stride + ((lane & 7) ^ (lane >> 3)) * 16);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(footprint > 0x7fffffff ? 0x7fffffff : footprint), 0x00020000);
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int t = 0; t < steps; ++t) {
+        char* dst = smem + (t & 1) * 65536;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int p = j * WAVES + wave;
+            size_t off = ((size_t)blockIdx.x * 512 + (size_t)p * 8) * row_stride + (size_t)t * 128;
+            off %= footprint - 65536;
+            off &= ~(size_t)15;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, (int)lane_off,
+                                                 (int)__builtin_amdgcn_readfirstlane((uint32_t)off), 0, 0);
+        }
+        if (PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    if (lane == 0 && wave == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WAVES>
+static int run_b(const char* name, const char* src, size_t footprint, size_t row_stride, unsigned long long* cyc, int grid) {
+    const int steps = 400;
+    CHECK(hipFuncSetAttribute((const void*)bdma_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(bdma_kernel<WAVES>, dim3(grid), dim3(WAVES * 64), 131072, 0, src, footprint, steps, row_stride, cyc);
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(bdma_kernel<WAVES>, dim3(grid), dim3(WAVES * 64), 131072, 0, src, footprint, steps, row_stride, cyc);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> h(grid);
+    CHECK(hipMemcpy(h.data(), cyc, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[grid / 2];
+    const double bytes = (double)grid * steps * 65536.0;
+    printf("%-54s %d waves: %8.1f us  %6.2f TB/s chip | median CU: %7.0f cycles per 64-KiB K-tile = %5.1f cycles per 1-KiB piece = %5.1f B/clk\n",
+           name, WAVES, ms * 1e3, bytes / (ms * 1e-3) / 1e12, med / steps, med / steps / 64.0, 65536.0 * steps / med);
+    return 0;
+}
+
 // the same stream through registers: global_load_dwordx4 (16 B per lane), optionally written on to LDS with ds_write_b128
 template <int WAVES, bool TO_LDS>
 __global__ __launch_bounds__(WAVES * 64) void reg_kernel(const char* __restrict__ src, size_t footprint, int steps, size_t row_stride,
@@ -133,6 +185,9 @@ int main() {
     if (run<8>("K=3072 rows, 192 MiB footprint", src, (size_t)192 << 20, 6144, cyc, 256)) return 1;
     if (run<8>("K=768 rows, 4 GiB footprint (HBM)", src, big, 1536, cyc, 256)) return 1;
     if (run<8>("one workgroup alone, 4 MiB footprint", src, (size_t)4 << 20, 1536, cyc, 1)) return 1;
+    if (run_b<8>("BUFFER_load ... lds, 48 MiB footprint", src, (size_t)48 << 20, 1536, cyc, 256)) return 1;
+    if (run_b<4>("BUFFER_load ... lds, 48 MiB footprint", src, (size_t)48 << 20, 1536, cyc, 256)) return 1;
+    if (run_b<8>("BUFFER_load ... lds, one workgroup alone, 4 MiB", src, (size_t)4 << 20, 1536, cyc, 1)) return 1;
     if (run_reg<8, false>("REGISTER loads only, 48 MiB footprint", src, (size_t)48 << 20, 1536, cyc, 256)) return 1;
     if (run_reg<8, true>("REGISTER loads + ds_write_b128, 48 MiB footprint", src, (size_t)48 << 20, 1536, cyc, 256)) return 1;
     if (run_reg<8, false>("REGISTER loads only, one workgroup alone, 4 MiB", src, (size_t)4 << 20, 1536, cyc, 1)) return 1;
