@@ -1224,7 +1224,11 @@ void gemm_tn256_group_kernel(const TnGroup G) {
     if (!found) return;
     c -= 1;                                            // the for statement stepped once more after the hit
     const TnProb& P = G.p[p];
-    const int tn = b / P.tiles_k, tk = b - tn * P.tiles_k;
+    // tile order inside a problem: walk the SHORTER tile dimension fastest, so that a contiguous item range (one XCD's share) touches few
+    // panels of the longer one -- fc2 (3 x 12 tiles): 27 consecutive items then read 3 Y + 9 X panels instead of 3 + 12
+    int tn, tk;
+    if (P.tiles_k > P.tiles_n) { tk = b / P.tiles_n; tn = b - tk * P.tiles_n; }
+    else { tn = b / P.tiles_k; tk = b - tn * P.tiles_k; }
     const int t0 = c * P.chunk_steps;
     const int nk = min(P.chunk_steps, P.nm - t0);
     if (nk <= 0) return;
