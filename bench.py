@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-staging", action="store_true", help="skip the two extra short regions that time H2D-fed and device-synthesised batches")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
+    ap.add_argument("--all-rows", action="store_true", help="no masked-row bound for the step: the last block's MLP runs on every token row (A/B of uvit_step_params.n_rows_hint)")
     ap.add_argument("--no-alone", action="store_true", help="skip the 3 extra single-stream steps that time the dominant kernel alone (profiling runs of the two-stream schedule)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce buckets (bf16 halves the xGMI bytes; AdamW accumulates in fp32 either way)")
@@ -244,12 +245,13 @@ def main():
         check(L.uvit_engine_set_tuning(engine.h, C.byref(tu)), "set_tuning")
     seed = 1000 + rank             # run_cyclical.py:315 seeds with seed + rank: every rank draws its own dropout / drop-path masks
 
-    feed = {"x": x, "mask": mask}      # what a step consumes (swapped by the input-staging regions below)
+    # masked patches of the batch, counted once on the host (every batch the staging regions feed has the same count): the step's row bound
+    feed = {"x": x, "mask": mask, "mask_rows": 0 if a.all_rows else int(mask.sum().item())}      # what a step consumes (swapped by the input-staging regions below)
 
     def step(i):
         depth = model.depth
         hp = make_step_params(list(range(depth // 2, depth)), opt, 3.0, 2.0, False, -1, True, True, 0.9998, True, world, seed, i,
-                              lambda_pretraining=1e-5, depth=depth)
+                              lambda_pretraining=1e-5, depth=depth, n_rows_hint=feed["mask_rows"])
         hp.lr = 2e-5       # warm-up-sized lr: random-init weights and fixed synthetic data, 2e-3 is the post-warm-up peak
         native_step(engine, reducer, feed["x"], feed["mask"], hp)
         opt.step_count += 1
@@ -314,7 +316,10 @@ def main():
                                    "AdamW, EMA 0.9998",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "model": a.model, "step_mfma_frac": round(value / world * GFLOP_BY_MODEL.get(a.model, GFLOP_PER_IMAGE) * 1e9 / PEAK_BF16, 4),
-                       "final_loss": round(float(stats[0]), 5)},
+                       "final_loss": round(float(stats[0]), 5),
+                       "last_block_mlp_rows": (f"{feed['mask_rows']} masked rows of {a.batch * 197} (host-side bound; same results as all rows)"
+                                               if feed["mask_rows"] and not stochastic else "all"),
+                       "step_mfma_frac_note": "algorithmic FLOPs of the reference's step (SURVEY 8d) / time / peak"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU | EPI_GELU_DG> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU; the student launch also stores gelu'(h))",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic_bytes(),

@@ -97,6 +97,11 @@ typedef struct uvit_step_params {
     /* target-builder variants (engine_for_cyclical.py:94-118): affine-free batch norm over (B, T) per channel, instance norm
      * over T per (sample, channel) on every target layer; instance norm of the layer average.  Base model only. */
     int32_t target_batch_norm, target_instance_norm, post_target_instance_norm;
+    /* Upper bound on the number of masked patches of this batch (the loader has bool_masked_pos on the host before the upload), 0 = not
+     * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the base model's last
+     * block runs its MLP -- forward, dgrads and wgrads -- on those rows alone; results equal the all-rows step.  A bound BELOW the true count
+     * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model ignores it. */
+    int32_t n_rows_hint;
 } uvit_step_params;
 
 int uvit_version(void);
@@ -134,6 +139,8 @@ int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float* out, int3
  * (B,N,C) f32), "xm" (after the attention branch), "loss", "grad_norm", "targets", "outputs", "count"};
  * two-stream model: also "x_cov", "xm_cov", "targets_cov", "outputs_cov". */
 void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer);
+/* Rows the last training step ran its last block's MLP on (uvit_step_params.n_rows_hint): 0 = every token row. */
+int uvit_engine_compact_rows(uvit_engine* e);
 
 /* ---- the training step, engine_for_cyclical.py:58-186 ---- */
 /* teacher forward (no grad) -> targets; student forward; loss; backward through lm_head + final norm */

@@ -138,6 +138,32 @@ def test_vitb_step_vs_oracle():
         torch.testing.assert_close(esd[n].cpu(), e[n], rtol=0, atol=2 * 2e-3 * 2e-4 + 1e-7)
 
 
+@pytest.mark.parametrize("dropout", [False, True])
+def test_last_block_on_masked_rows_equals_all_rows(dropout):
+    """uvit_step_params.n_rows_hint (include/uvit.h): with a host-side bound on the masked patches -- the loader's mask is a CPU tensor --
+    the last block's MLP runs on those rows only.  Same model, same batch, same seeds: the step must give the loss and the gradients of the
+    all-rows step (the fc1 / fc2 weight gradients sum fewer zero rows in another order, everything else is the same arithmetic), with and
+    without dropout / drop-path (the per-sample drop-path scale and the LayerScale gradient go through the row list), and with ragged masks
+    (another count per sample).  ViT-B/16, B = 8: 8 x 197 = 1,576 token rows, 529 masked -> 576 compact rows."""
+    cfg = vo.VitConfig(init_values=0.1, attn_drop_rate=0.05 if dropout else 0.0, drop_path_rate=0.25 if dropout else 0.0)
+    x = closed_form_images("rows", 8, 224)
+    mask = exact_masks(8, 196, 75, 5)
+    mask[3, :] = False; mask[3, :4] = True          # ragged: 4 masked patches in one sample, 75 in the others
+    res = {}
+    for mode in ("all", "rows"):
+        model, _ = native_model(cfg)
+        ema, opt = native_trainer(model)
+        if dropout:
+            model.train()
+        batch = (x.cuda(), mask.cuda()) if mode == "all" else (x, mask)       # a CPU mask is counted on the host: the row bound
+        st = native_steps(model, ema, opt, [batch], list(range(6, 12)))[0]
+        res[mode] = (st, {n: q.grad.detach().float().cpu().clone() for n, q in model.named_parameters()})
+        assert (model._engine.compact_rows() > 0) == (mode == "rows")
+    (sa, ga), (sr, gr) = res["all"], res["rows"]
+    assert sr["loss"] == pytest.approx(sa["loss"], rel=1e-6) and sr["grad_norm"] == pytest.approx(sa["grad_norm"], rel=1e-5)
+    assert_grads_close(gr, ga, max_tol=1e-4, l2_tol=1e-4, what="[masked rows vs all rows] ")
+
+
 @pytest.mark.parametrize("variant", ["l2_loss", "beta_small", "loss_scale", "no_post_ln", "no_clip", "ema_off", "ragged_masks"])
 def test_step_hyperparameter_variants_vs_oracle(variant):
     """The knobs of train_one_epoch that BASELINE's recipes toggle (engine_for_cyclical.py:24-32, 147-163, 182-185;

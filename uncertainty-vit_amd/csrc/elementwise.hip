@@ -124,7 +124,10 @@ template <int NV>
 __global__ __launch_bounds__(256)
 void ls_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, const float* __restrict__ gamma,
                    const float* __restrict__ rowscale, bf16* __restrict__ dy, float* __restrict__ dgamma,
-                   float* __restrict__ dbias, int M, int C, int tokens, int nrep, size_t rep_stride) {
+                   float* __restrict__ dbias, int M, int C, int tokens, int nrep, size_t rep_stride,
+                   const int* __restrict__ rowidx, const int* __restrict__ count) {
+    // rowidx != nullptr: COMPACT output -- row r of dy belongs to residual-stream row rowidx[r] (dx, y and the drop-path sample are taken
+    // there); rows r >= *count are padding and get zeros
     __shared__ float red[4][64 * 4];
     dgamma += (size_t)(blockIdx.x % nrep) * rep_stride; dbias += (size_t)(blockIdx.x % nrep) * rep_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2;
@@ -132,15 +135,23 @@ void ls_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y, con
 #pragma unroll
     for (int k = 0; k < NV; ++k) { ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k]; }
     const int row_end = min((int)(blockIdx.x + 1) * CP_ROWS, M);
+    const int n_valid = rowidx ? min(*count, M) : M;
     for (int row = blockIdx.x * CP_ROWS + wave; row < row_end; row += 4) {
-        const float dp = rowscale ? rowscale[row / tokens] : 1.0f;
+        if (row >= n_valid) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (lane + 64 * k < nv) ((bf16x4*)(dy + (size_t)row * C))[lane + 64 * k] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+            continue;
+        }
+        const int xr = rowidx ? rowidx[row] : row;
+        const float dp = rowscale ? rowscale[xr / tokens] : 1.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nv) {
-                const float4 d = ((const float4*)(dx + (size_t)row * C))[i];
+                const float4 d = ((const float4*)(dx + (size_t)xr * C))[i];
                 const float4 g = ((const float4*)gamma)[i];
-                const bf16x4 yy = ((const bf16x4*)(y + (size_t)row * C))[i];
+                const bf16x4 yy = ((const bf16x4*)(y + (size_t)xr * C))[i];
                 const float e0 = d.x * dp, e1 = d.y * dp, e2 = d.z * dp, e3 = d.w * dp;
                 ag[k].x += e0 * bf2f(yy[0]); ag[k].y += e1 * bf2f(yy[1]); ag[k].z += e2 * bf2f(yy[2]); ag[k].w += e3 * bf2f(yy[3]);
                 bf16x4 o = {f2bf(e0 * g.x), f2bf(e1 * g.y), f2bf(e2 * g.z), f2bf(e3 * g.w)};
@@ -344,10 +355,18 @@ int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, f
     return uvit_check_launch();
 }
 int uvit_ls_bwd_launch(const float* dx, const void* y, const float* gamma, const float* rowscale, void* dy,
-                       float* dgamma, float* dbias, int M, int C, int tokens, int nrep, size_t rep_stride, hipStream_t s) {
-    if (C % 4 || C > CP_MAXV * 256) return UVIT_ERR_SHAPE;
+                       float* dgamma, float* dbias, int M, int C, int tokens, int nrep, size_t rep_stride, hipStream_t s,
+                       const int* rowidx, const int* count) {
+    if (C % 4 || C > CP_MAXV * 256 || (rowidx && !count)) return UVIT_ERR_SHAPE;
     CP_DISPATCH(ls_bwd_kernel, C, dim3((M + CP_ROWS - 1) / CP_ROWS), dim3(256), 0, s, dx, (const bf16*)y, gamma, rowscale,
-                       (bf16*)dy, dgamma, dbias, M, C, tokens, nrep > 0 ? nrep : 1, rep_stride);
+                       (bf16*)dy, dgamma, dbias, M, C, tokens, nrep > 0 ? nrep : 1, rep_stride, rowidx, count);
+    return uvit_check_launch();
+}
+__global__ void rows_guard_kernel(const int* __restrict__ count, int limit, float* __restrict__ loss) {
+    if (*count > limit) loss[0] = __builtin_nanf("");
+}
+int uvit_rows_guard_launch(const int* count, int limit, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(rows_guard_kernel, dim3(1), dim3(1), 0, s, count, limit, loss);
     return uvit_check_launch();
 }
 int uvit_colsum_launch(const void* y, int ld, int col0, int ncols, int M, float* out, int nrep, size_t rep_stride, hipStream_t s) {

@@ -166,6 +166,7 @@ struct uvit_engine {
     bool slab_started;
     bool last_dropout; uint32_t last_seed, last_it;
     int ls_prefused = -1;   // layer whose MLP-branch LayerScale backward was already done by layer+1's fused LayerNorm backward
+    int compact_R = 0;      // > 0: this step runs the last block's MLP on the masked rows only, in R (multiple of 64) compact rows (uvit_step_params.n_rows_hint)
     // second stream: teacher forward beside student forward; wgrad GEMMs beside the dgrad chain
     bool dual = true;
     hipStream_t aux = nullptr;
@@ -457,9 +458,12 @@ static const float* dp_ptr(uvit_engine* e, bool on, int l, int st, int branch, i
     return e->dp_scales + (size_t)(nbr * l + k) * Bc;
 }
 
+// R > 0 (base model, student's last block of a training step): the MLP branch runs on the R compact rows of the masked-patch list only --
+// LN2 gathers them, fc1 / fc2 are R-row GEMMs and the residual epilogue of fc2 reads x_mid and writes x_out / the saved branch output at the
+// listed rows (the other rows of x_out are never read: the head and the final-norm backward go through the same list).
 static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x_in, float* x_mid, float* x_out,
                          LayerActs& a, bool save, const float* biasP, bool dp_on, float pdrop, uint32_t seed, int Bc,
-                         hipStream_t s) {
+                         hipStream_t s, int R = 0) {
     const LayerOff& o = e->lo.L[l];
     const int M = Bc * e->N, C = e->C, Hd = e->Hd, S = e->S;
     const size_t Mp = e->Mpad;                                   // row offset of stream 1
@@ -480,17 +484,19 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
         CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
     }
-    CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
+    if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
+    else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
-    const bool prof = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    const bool prof = R == 0 && e->prof_on && e->prof_used + 2 <= e->prof_ev.size();    // (only full-size fc1 launches are timed)
     if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
-    CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mall, Hd, C, C, C, &f1, s));
+    CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, R > 0 ? R : Mall, Hd, C, C, C, &f1, s));
     if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
     for (int st = 0; st < S; ++st) {
         GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
         f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
-        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, M, C, Hd, Hd, Hd, &f2, s));
+        if (R > 0) { f2.rowmap = e->rowidx; f2.rowcount = e->count; }
+        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, R > 0 ? R : M, C, Hd, Hd, Hd, &f2, s));
     }
     return UVIT_OK;
 }
@@ -530,8 +536,9 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
     int n_t = 0;
     for (int l = 0; l < e->cfg.depth; ++l) {
         if (use_saved) {
+            const bool last_compact = save_student && !teacher && l == e->cfg.depth - 1 && e->compact_R > 0;
             CHECK(forward_layer(e, w, l, e->X[l], e->XM[l], e->X[l + 1], e->acts[l], save_student && !teacher, biasP, dp_on,
-                                pdrop, aseed, Bc, s));
+                                pdrop, aseed, Bc, s, last_compact ? e->compact_R : 0));
         } else {
             float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
             CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s));
@@ -625,6 +632,8 @@ extern "C" int uvit_engine_head(uvit_engine* e, int which, int all_tokens, float
     return UVIT_OK;
 }
 
+extern "C" int uvit_engine_compact_rows(uvit_engine* e) { return e ? e->compact_R : 0; }
+
 extern "C" void* uvit_engine_ws_ptr(uvit_engine* e, const char* name, int layer) {
     if (!e || !name) return nullptr;
     const std::string n(name);
@@ -661,6 +670,17 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     CHECK(uvit_zero_launch(e->loss, 64 * sizeof(float), ts));
     CHECK(uvit_zero_launch(e->dXa, e->rows_alloc() * C * sizeof(float), ts));
     e->slab_started = false; e->ls_prefused = -1;
+    // the last block's MLP on the masked rows only (see forward_layer): base model, a row bound from the host, and fewer rows than tokens
+    e->compact_R = 0;
+    if (e->S == 1 && hp->n_rows_hint > 0) {
+        const int R = (int)roundup((size_t)(hp->n_rows_hint < BP ? hp->n_rows_hint : BP), 64);
+        if (R >= 512 && R < e->M) {
+            e->compact_R = R;
+            // its LayerNorm backward writes the residual-stream gradient and the proj branch's dY at the listed rows only: the rest is zero
+            CHECK(uvit_zero_launch(e->dXb, e->rows_alloc() * C * sizeof(float), ts));
+            CHECK(uvit_zero_launch(e->dY2[(e->cfg.depth - 1) & 1], e->rows_alloc() * C * sizeof(bf16), ts));
+        }
+    }
     HIPCHECK(hipMemcpyAsync(e->mask_copy, mask, (size_t)BP * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     CHECK(uvit_mask_compact_launch(mask, e->rowidx, e->count, Bc, e->P, s));
     CHECK(uvit_im2col_launch(images, e->cols, Bc, e->cfg.in_chans, e->cfg.img_size, e->cfg.patch_size, s));
@@ -679,6 +699,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     if (hp->var_w0 > 0.f)      // variance term on the mean-stream outputs (engine_for_cyclical.py:130-139); std_loss0 -> loss[4]
         CHECK(uvit_variance_loss_launch(e->outputs[0], e->count, hp->var_w0, hp->var_margin0, ls, e->var_scratch, e->loss, e->loss + 4,
                                         e->dout[0], BP, C, s));
+    if (e->compact_R > 0) CHECK(uvit_rows_guard_launch(e->count, e->compact_R, e->loss, s));     // more masked rows than the host promised
     if (e->S == 2)
         CHECK(uvit_wasserstein_loss_launch(e->outputs[0], e->outputs[1], e->targets[0], e->targets[1], e->count, hp->lambda_pretraining,
                                            ls, e->wl_scratch, e->loss, e->dout[0], e->dout[1], BP, C, s));
@@ -728,13 +749,17 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     };
     if (e->dual && l + 2 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 2], 0));
     bf16 *dY1 = e->dY1[par], *dY2 = e->dY2[par], *dH = e->dH[par], *dqkv = e->dqkv[par];
+    // last block with a masked-row list (see forward_layer): its MLP branch -- LayerScale backward, both dgrads, both wgrads, LN2 backward --
+    // runs on the R compact rows; dY1 / dH / dLN are compact, the LN2 backward scatters into the (zeroed) dense dXb / dY2
+    const int R = (l == e->cfg.depth - 1) ? e->compact_R : 0;
+    const int Mmlp = R > 0 ? R : Mall, Mmlp_red = R > 0 ? R : Mred;
     // weight gradients: one grouped launch per layer (bias column sums of fc1 / q / v fused) when every Linear has
     // 256-multiple dimensions; otherwise one launch per Linear as the operands become available
     TnProb wg[UVIT_TN_GROUP_MAX];
     int nwg = 0;
     {
-        TnProb& f2 = wg[nwg++]; f2.Y = dY1; f2.X = a.a; f2.C = g + o.fc2w; f2.M = Mred; f2.Nn = C; f2.Kk = Hd; f2.ldy = C; f2.ldx = Hd; f2.ldc = Hd;
-        TnProb& f1 = wg[nwg++]; f1.Y = dH; f1.X = a.ln2; f1.C = g + o.fc1w; f1.M = Mred; f1.Nn = Hd; f1.Kk = C; f1.ldy = Hd; f1.ldx = C; f1.ldc = C;
+        TnProb& f2 = wg[nwg++]; f2.Y = dY1; f2.X = a.a; f2.C = g + o.fc2w; f2.M = Mmlp_red; f2.Nn = C; f2.Kk = Hd; f2.ldy = C; f2.ldx = Hd; f2.ldc = Hd;
+        TnProb& f1 = wg[nwg++]; f1.Y = dH; f1.X = a.ln2; f1.C = g + o.fc1w; f1.M = Mmlp_red; f1.Nn = Hd; f1.Kk = C; f1.ldy = Hd; f1.ldx = C; f1.ldc = C;
         f1.bias = RP(o.fc1b); f1.bias_end = Hd;
         for (int st = 0; st < S; ++st) {
             TnProb& pj = wg[nwg++]; pj.Y = dY2 + st * Mp * C; pj.X = a.attn + st * Mp * C; pj.C = g + off_projw(o, st);
@@ -748,31 +773,35 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     // (the LayerScale backward of a branch rides in the LayerNorm backward that produces its input; in the two-stream
     //  model that kernel is launched once per stream, because drop-path scales and the proj bias differ per stream)
     const bool fuse_ls = true;
-    if (e->ls_prefused != l)
+    if (R > 0)       // compact dY1 from the residual-stream gradient and the saved branch output at the listed rows (S == 1)
+        CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), R, C, e->N, NREP,
+                                 e->n_nd, s, e->rowidx, e->count));
+    else if (e->ls_prefused != l)
         for (int st = 0; st < S; ++st)
             CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
                                      RP(o.g2), RP(o.fc2b), M, C, e->N, NREP, e->n_nd, s));
     e->ls_prefused = -1;
     if (!grouped) {
         CHECK(handoff(0));
-        CHECK(GEMM_TN(dY1, a.a, Mred, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
+        CHECK(GEMM_TN(dY1, a.a, Mmlp_red, C, Hd, C, Hd, g + o.fc2w, Hd, 1, ws));
     }
     GemmEpi d1; d1.out = dH; d1.aux = a.h; d1.ldo = Hd;
-    CHECK(GEMM_NT(EPI_MULAUX, dY1, wt + o.fc2w, Mall, Hd, C, C, C, &d1, s));      // dH = (dY.W2) * gelu'(h)
+    CHECK(GEMM_NT(EPI_MULAUX, dY1, wt + o.fc2w, Mmlp, Hd, C, C, C, &d1, s));      // dH = (dY.W2) * gelu'(h)
     if (!grouped) {
         CHECK(handoff(1));
-        CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mall, RP(o.fc1b), NREP, e->n_nd, ws));
-        CHECK(GEMM_TN(dH, a.ln2, Mred, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
+        CHECK(uvit_colsum_launch(dH, Hd, 0, Hd, Mmlp, RP(o.fc1b), NREP, e->n_nd, ws));
+        CHECK(GEMM_TN(dH, a.ln2, Mmlp_red, Hd, C, Hd, C, g + o.fc1w, C, 1, ws));
     }
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
-    CHECK(GEMM_NT(EPI_BF16, dH, wt + o.fc1w, Mall, C, Hd, Hd, Hd, &d2, s));
+    CHECK(GEMM_NT(EPI_BF16, dH, wt + o.fc1w, Mmlp, C, Hd, Hd, Hd, &d2, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
     if (fuse_ls) {
         for (int st = 0; st < S; ++st) {
             const size_t ro = st * Mp, eo = ro * C;
             CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->XM[l] + eo, a.mean2 + ro, a.rstd2 + ro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
                                         RP(o.n2w), RP(o.n2b), a.projout + eo, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + eo,
-                                        RP(o.g1), RP(off_projb(o, st)), e->N, M, C, NREP, e->n_nd, s));
+                                        RP(o.g1), RP(off_projb(o, st)), e->N, R > 0 ? R : M, C, NREP, e->n_nd, s,
+                                        R > 0 ? e->rowidx : nullptr, R > 0 ? e->count : nullptr));
         }
     } else {
         CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));

@@ -178,7 +178,7 @@ __device__ __forceinline__ void epi_sync() { asm volatile("s_waitcnt lgkmcnt(0)"
 // row-indexed epilogue operands of one block (DGELU: h, RESID: the residual rows), requested before the block is
 // staged so that their latency overlaps the LDS round trip instead of following it
 template <int MODE>
-struct EpiPre { bf16x8 h[2]; float4 r[4]; };
+struct EpiPre { bf16x8 h[2]; float4 r[4]; int mrow[4]; };     // mrow: RESID over a row list: the residual-stream row of each read-back row (-1: padding)
 
 template <int MODE>
 __device__ __forceinline__ EpiPre<MODE> epi_prefetch(const GemmEpi& e, int lane, int mb, int nb, int M, int N) {
@@ -192,9 +192,13 @@ __device__ __forceinline__ EpiPre<MODE> epi_prefetch(const GemmEpi& e, int lane,
         }
     } else if constexpr (MODE == EPI_RESID) {
         const int n = nb + (lane & 15) * 4;
+        const int nvalid = e.rowmap ? min(*e.rowcount, M) : M;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int m = mb + 4 * i + (lane >> 4); m = m < M ? m : M - 1;
+            int m = mb + 4 * i + (lane >> 4);
+            p.mrow[i] = m;
+            if (e.rowmap) { p.mrow[i] = m < nvalid ? e.rowmap[m] : -1; m = p.mrow[i] < 0 ? 0 : p.mrow[i]; }
+            else m = m < M ? m : M - 1;
             p.r[i] = *(const float4*)(e.resid + (size_t)m * e.ldo + (n < N ? n : 0));
         }
     }
@@ -272,9 +276,11 @@ __device__ __forceinline__ void epi_flush(const GemmEpi& e, const EpiCols<MODE>&
                 *(float4*)((float*)e.out + (size_t)m * e.ldo + n) = make_float4(y0, y1, y2, y3);
             } else if constexpr (MODE == EPI_RESID) {
                 // x_out = resid + droppath[b] * gamma * (acc + bias)   (modeling_finetune.py:295-298)
-                const size_t o = (size_t)m * e.ldo + n;
+                const int mr = pre.mrow[i];                    // = m, or the residual-stream row of compact row m
+                if (mr < 0) continue;
+                const size_t o = (size_t)mr * e.ldo + n;
                 const float4 r = pre.r[i];
-                const float dp = e.rowscale ? e.rowscale[(m + e.row0) / e.tokens] : 1.0f;
+                const float dp = e.rowscale ? e.rowscale[(mr + e.row0) / e.tokens] : 1.0f;
                 if (e.out2) {
                     const bf16x4 yv = {f2bf(y0), f2bf(y1), f2bf(y2), f2bf(y3)};
                     *(bf16x4*)((bf16*)e.out2 + o) = yv;
@@ -1341,7 +1347,7 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     // 256-row tiles that overflow whole rounds of the CUs by only a few tiles would run a nearly empty last round: the
     // overflowing row tiles go to the 128x128 kernel instead (second launch below)
     int m_tail = 0;
-    if (variant == 1 && mt == 4 && nt_variant == 3 && mode != EPI_PATCH) {
+    if (variant == 1 && mt == 4 && nt_variant == 3 && mode != EPI_PATCH && !epi->rowmap) {      // (a row list does not split: its rows are not an offset apart)
         const int tiles_n = N / T_BN, tiles = ((M + T_BM - 1) / T_BM) * tiles_n;
         const int rounds = tiles / g_num_cu, over = tiles - rounds * g_num_cu;
         // (round 3 tried half a round of overflow -- QKV at bs = 128: 891 tiles = 3 rounds + 123: 93.2 -> 88.9 us alone, but inside the

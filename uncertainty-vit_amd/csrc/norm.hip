@@ -338,12 +338,12 @@ int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const 
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                           const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
-                          int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
-    if (ln_shape_ok(M, C) || tokens <= 0) return UVIT_ERR_SHAPE;
+                          int M, int C, int nrep, size_t rep_stride, hipStream_t s, const int* rowidx, const int* count) {
+    if (ln_shape_ok(M, C) || tokens <= 0 || (rowidx && !count)) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
     const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
-                       (const int*)nullptr, (const int*)nullptr, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
+                       rowidx, count, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,

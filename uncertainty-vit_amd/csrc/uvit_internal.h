@@ -23,6 +23,11 @@ struct GemmEpi {
     int patches = 1;                 // PATCH: rows per sample in the GEMM
     int row0 = 0;                    // RESID: sample index of GEMM row m is (m + row0) / tokens (row-split launches)
     int ngroup = 0;                  // 256x256 kernel: column tiles per row-tile group of the XCD-aware tile order (0 = 6)
+    // RESID over a COMPACT row list (the student's last MLP on the masked rows only): GEMM row m stands for residual-stream row
+    // rowmap[m] -- resid is read and out / out2 are written THERE, the drop-path sample is rowmap[m] / tokens; rows m >= *rowcount
+    // are padding and write nothing
+    const int* rowmap = nullptr;
+    const int* rowcount = nullptr;
 };
 
 // gemm.hip
@@ -92,7 +97,8 @@ int uvit_ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, c
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                           const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
-                          int M, int C, int nrep, size_t rep_stride, hipStream_t s);
+                          int M, int C, int nrep, size_t rep_stride, hipStream_t s,
+                          const int* rowidx = nullptr, const int* count = nullptr);   // row list: dy / mean / rstd are compact, everything else lives at rowidx[row]
 int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* rowidx, const int* count,
                                const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
                                int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
@@ -118,7 +124,8 @@ int uvit_relpos_scatter_launch(const float* slab, int nslab, const int* index, f
                                hipStream_t s);
 int uvit_ls_bwd_launch(const float* dx, const void* branch_bf16, const float* gamma, const float* rowscale,
                        void* dy_bf16, float* dgamma, float* dbias, int M, int C, int tokens, int nrep, size_t rep_stride,
-                       hipStream_t s);
+                       hipStream_t s, const int* rowidx = nullptr, const int* count = nullptr);   // row list: dy is compact, dx / branch live at rowidx[row]
+int uvit_rows_guard_launch(const int* count, int limit, float* loss, hipStream_t s);   // *count > limit: loss <- NaN (the step is then skipped like any non-finite one)
 int uvit_colsum_launch(const void* y_bf16, int ld, int col0, int ncols, int M, float* out, int nrep, size_t rep_stride,
                        hipStream_t s);
 int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,

@@ -107,18 +107,20 @@ class DevicePrefetcher:
         self.loader, self.device = loader, torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.mask_rows = 0     # masked patches of the batch being handed out, counted on the host before its upload (0 = unknown)
 
     def __len__(self):
         return len(self.loader)
 
     def _upload(self, item):
         (samples, mask), label = item
+        rows = int(mask.sum()) if (torch.is_tensor(mask) and not mask.is_cuda) else 0      # free on the host; a device mask would need a sync
         if not self.on_gpu:
-            return (samples.to(self.device).float().contiguous(), mask.to(self.device)), label
+            return ((samples.to(self.device).float().contiguous(), mask.to(self.device)), label), rows
         with torch.cuda.stream(self.stream):
             samples = samples.to(self.device, non_blocking=True).float().contiguous()
             mask = mask.to(self.device, non_blocking=True)
-        return (samples, mask), label
+        return ((samples, mask), label), rows
 
     def __iter__(self):
         it = iter(self.loader)
@@ -127,7 +129,7 @@ class DevicePrefetcher:
         except StopIteration:
             return
         while ahead is not None:
-            cur = ahead
+            cur, self.mask_rows = ahead
             if self.on_gpu:
                 torch.cuda.current_stream(self.device).wait_stream(self.stream)
                 for t in cur[0]:
@@ -161,7 +163,10 @@ def native_step(engine, reducer, samples, mask, hp):
 
 def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
                      post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5,
-                     depth=None, target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False):
+                     depth=None, target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False,
+                     n_rows_hint=0):
+    """n_rows_hint: an upper bound on the batch's masked patches known on the HOST (0 = unknown): the base model's last block then runs
+    its MLP on those rows only (include/uvit.h, uvit_step_params.n_rows_hint); the results are those of the all-rows step."""
     hp = StepParams()
     if len(target_layers) > MAX_DEPTH:
         raise ValueError(f"at most {MAX_DEPTH} target layers")
@@ -191,6 +196,7 @@ def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_
     hp.seed, hp.it = int(seed) & 0xFFFFFFFF, int(it) & 0xFFFFFFFF
     hp.train_dropout = int(bool(train_dropout))
     hp.lambda_pretraining = float(lambda_pretraining)
+    hp.n_rows_hint = max(int(n_rows_hint or 0), 0)
     return hp
 
 
@@ -305,7 +311,8 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     sched_dev = None
 
     cur_decay = decay
-    for step, (batch, _) in enumerate(metric_logger.log_every(DevicePrefetcher(data_loader, device), print_freq, header)):
+    prefetcher = DevicePrefetcher(data_loader, device)
+    for step, (batch, _) in enumerate(metric_logger.log_every(prefetcher, print_freq, header)):
         it = start_steps + step  # global training iteration
         # per-step lr / weight-decay (engine_for_cyclical.py:47-53): the param groups keep showing the current values
         if lr_schedule_values is not None or wd_schedule_values is not None:
@@ -336,7 +343,8 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
         hp = make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_scale, target_layer_norm_last,
                               post_target_layer_norm, cur_decay, do_ema, world, seed, it, lambda_pretraining=lambda_pretraining,
                               depth=net.depth, target_batch_norm=target_batch_norm, target_instance_norm=target_instance_norm,
-                              post_target_instance_norm=post_target_instance_norm)
+                              post_target_instance_norm=post_target_instance_norm,
+                              n_rows_hint=prefetcher.mask_rows)      # (mask dropout only removes rows: still an upper bound)
         if scalars is not None and step < len(scalars):
             assert scalars[step] == (hp.lr, hp.weight_decay, hp.ema_decay if do_ema else -1.0), (scalars[step], hp.lr, hp.weight_decay, hp.ema_decay)
             if sched_dev is None:

@@ -109,6 +109,10 @@ class NativeEngine:
     def sync_shadows(self, which=3):
         check(lib().uvit_engine_sync_shadows(self.h, which, cur_stream()), "sync_shadows")
 
+    def compact_rows(self):
+        """Rows the last training step ran its last block's MLP on (0 = every token row)."""
+        return int(lib().uvit_engine_compact_rows(self.h))
+
     def ws_tensor(self, name, layer, shape, dtype=torch.float32):
         p = lib().uvit_engine_ws_ptr(self.h, name.encode(), layer)
         if not p:

@@ -53,7 +53,8 @@ class StepParams(C.Structure):
                 ("seed", C.c_uint32), ("it", C.c_uint32), ("train_dropout", C.c_int32), ("lambda_pretraining", C.c_float),
                 ("sched_dev", C.c_void_p), ("sched_len", C.c_int32), ("sched_index", C.c_int32),
                 ("layer_results_fc", C.c_int32), ("var_w0", C.c_float), ("var_margin0", C.c_float),
-                ("target_batch_norm", C.c_int32), ("target_instance_norm", C.c_int32), ("post_target_instance_norm", C.c_int32)]
+                ("target_batch_norm", C.c_int32), ("target_instance_norm", C.c_int32), ("post_target_instance_norm", C.c_int32),
+                ("n_rows_hint", C.c_int32)]
 
 
 class WgradProblem(C.Structure):
@@ -98,6 +99,7 @@ _PROTOTYPES = {
     "uvit_engine_forward_features": (_i, [_vp, _i, _vp, _vp, _i, _i, _u32, _u32, _vp]),
     "uvit_engine_head": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "uvit_engine_ws_ptr": (_vp, [_vp, C.c_char_p, _i]),
+    "uvit_engine_compact_rows": (_i, [_vp]),
     "uvit_step_begin": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "uvit_step_backward_layer": (_i, [_vp, _i, _vp, _vp]),
     "uvit_step_backward_embed": (_i, [_vp, _vp]),
