@@ -598,8 +598,8 @@ extern "C" int uvit_engine_forward_features(uvit_engine* e, int which, const flo
 }
 
 // final norm (shared) + drop cls + masked-row gather + per-stream head (modeling_cyclical.py:207,215-225)
-static int head_forward(uvit_engine* e, const Weights& w, int Bc, int st, bool all_tokens, float* out, hipStream_t s) {
-    const int BP = Bc * e->P;
+static int head_forward(uvit_engine* e, const Weights& w, int Bc, int st, bool all_tokens, float* out, hipStream_t s, int rows = 0) {
+    const int BP = rows > 0 ? rows : Bc * e->P;        // rows > 0: a host-side bound on the masked rows (training step with n_rows_hint)
     const float* x = e->X[e->cfg.depth] + (size_t)st * e->Mpad * e->C;
     const size_t lmw = st ? e->lo.clmw : e->lo.lmw, lmb = st ? e->lo.clmb : e->lo.lmb;
     if (all_tokens) {
@@ -691,7 +691,8 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_teacher, ts));
     CHECK(run_forward(e, 0, images, mask, Bc, true, hp->train_dropout != 0, hp->seed, hp->it, nullptr, true, s));
     Weights w{e->buf.params, (const bf16*)e->buf.params_bf16};
-    for (int st = 0; st < e->S; ++st) CHECK(head_forward(e, w, Bc, st, false, e->outputs[st], s));
+    const int Rh = e->compact_R > 0 ? e->compact_R : BP;      // rows of the head and of its backward (rows beyond the device-side count are zero)
+    for (int st = 0; st < e->S; ++st) CHECK(head_forward(e, w, Bc, st, false, e->outputs[st], s, e->compact_R));
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_teacher, 0));
     // loss + dLoss/dOutputs: engine_for_cyclical.py:130-163 (+ WassersteinLoss for the two-stream model, :152-161)
     const float ls = hp->loss_scale == -1.0f ? 1.0f : hp->loss_scale;
@@ -708,14 +709,14 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
     for (int st = 0; st < e->S; ++st) {
         const size_t lmw = st ? lo.clmw : lo.lmw, lmb = st ? lo.clmb : lo.lmb;
-        CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, BP, RP(lmb), NREP, e->n_nd, s));
-        CHECK(GEMM_TN(e->dout[st], e->normed[st], e->BPpad, C, C, C, C, g + lmw, C, 1, s));
+        CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, Rh, RP(lmb), NREP, e->n_nd, s));
+        CHECK(GEMM_TN(e->dout[st], e->normed[st], e->compact_R > 0 ? e->compact_R : e->BPpad, C, C, C, C, g + lmw, C, 1, s));
         GemmEpi d; d.out = e->dnormed[st]; d.ldo = C;
-        CHECK(GEMM_NT(EPI_BF16, e->dout[st], wt + lmw, BP, C, C, C, C, &d, s));
+        CHECK(GEMM_NT(EPI_BF16, e->dout[st], wt + lmw, Rh, C, C, C, C, &d, s));
         // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
         CHECK(uvit_ln_bwd_scatter_launch(e->dnormed[st], e->X[e->cfg.depth] + (size_t)st * e->Mpad * C, e->rowidx, e->count,
                                          e->meanF[st], e->rstdF[st], e->buf.params + lo.normw, e->dXa + (size_t)st * e->Mpad * C,
-                                         RP(lo.normw), RP(lo.normb), BP, C, NREP, e->n_nd, s));
+                                         RP(lo.normw), RP(lo.normb), Rh, C, NREP, e->n_nd, s));
     }
     return UVIT_OK;
 }
