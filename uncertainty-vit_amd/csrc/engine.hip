@@ -541,11 +541,13 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
                                 pdrop, aseed, Bc, s, last_compact ? e->compact_R : 0));
         } else {
             float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
-            CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s));
             // `[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): a layer listed twice is summed twice and the
             // mean divides by len(target_layers); the host has already mapped negative indices and refused out-of-range ones
             const bool dense = hp_targets->target_batch_norm || hp_targets->target_instance_norm ||
                                hp_targets->post_target_instance_norm || !hp_targets->target_layer_norm_last;
+            // the teacher's last block feeds nothing but the target rows: with a masked-row bound its MLP runs on those rows only
+            const int Rt = (l == e->cfg.depth - 1 && !dense) ? e->compact_R : 0;
+            CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s, Rt));
             if (dense && (e->S != 1 || Bc != e->B)) return UVIT_ERR_ARG;
             for (int k = 0; k < hp_targets->n_target_layers; ++k) {
                 if (hp_targets->target_layers[k] != l) continue;
