@@ -274,6 +274,27 @@ def test_device_prefetcher_passes_batches_through_in_order():
     assert list(DevicePrefetcher([], "cpu")) == []
 
 
+def test_prefetcher_counts_the_masked_rows_of_the_batch_it_hands_out():
+    """The host-side row bound of the step (uvit_step_params.n_rows_hint) is the number of masked patches of the batch being consumed,
+    counted on the CPU mask before the upload -- not of the batch already prefetched behind it."""
+    from uncertainty_vit_amd.engine_for_cyclical import DevicePrefetcher, make_step_params
+    masks = [torch.zeros(2, 4, 4, dtype=torch.bool) for _ in range(3)]
+    for i, m in enumerate(masks):
+        m.view(-1)[: 3 * i + 1] = True
+    pf = DevicePrefetcher([((torch.zeros(2, 3, 4, 4), m), 0) for m in masks], "cpu")
+    assert pf.mask_rows == 0
+    seen = []
+    for (_, m), _ in pf:
+        seen.append((pf.mask_rows, int(m.sum())))
+    assert seen == [(1, 1), (4, 4), (7, 7)]
+
+    class Opt:
+        param_groups = [dict(lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)]
+        step_count = 0
+    hp = make_step_params([1], Opt(), 3.0, 2.0, False, -1, True, True, 0.9998, True, 1, 0, 0, n_rows_hint=7)
+    assert hp.n_rows_hint == 7 and make_step_params([1], Opt(), 3.0, 2.0, False, -1, True, True, 0.9998, True, 1, 0, 0).n_rows_hint == 0
+
+
 def test_bench_self_launch_command_and_clean_failure_without_gpus():
     """`python bench.py --gpus N` must work when invoked directly: it builds a torch.distributed.run
     command for N ranks on 127.0.0.1 before touching the GPU, and on a machine with fewer GPUs it exits 2 with a message
