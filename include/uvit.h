@@ -240,9 +240,13 @@ int uvit_op_attn_bwd(const void* qkv, const void* o_fwd, const void* d_o, const 
  * gradient of the PRE-ELU covariance QKV (ELU' folded in).  biasP / lse units as for uvit_op_attn_fwd. */
 int uvit_op_attn2_fwd(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse, int B, int H,
                       int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, uvit_stream stream);
+/* Backward, fused since round 4 (one recomputation of P for all six gradients), same contract as uvit_op_attn_bwd: the score
+ * gradients leave once, as bf16, into ds_workspace (uvit_op_attn2_bwd_ws_bytes(B, H, N) bytes; only needed with dbias_slab) and a
+ * second kernel sums them over the batch into dbias_slab = ONE (H, NP, NP) slab laid out [h][key][q]. */
+int64_t uvit_op_attn2_bwd_ws_bytes(int B, int H, int N);
 int uvit_op_attn2_bwd(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
                       const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* dbias_slab,
-                      int accumulate_slab, int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
+                      int accumulate_slab, void* ds_workspace, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
                       uint32_t layer, uvit_stream stream);
 int uvit_op_relpos_gather(const float* table, const int32_t* index, float* biasP, int H, int N, int NP, uvit_stream stream);
 int uvit_op_relpos_scatter(const float* slab, int nslab, const int32_t* index, float* dtable, int H, int N, int NP,

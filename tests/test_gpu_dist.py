@@ -80,13 +80,13 @@ def test_wasserstein_attention_fwd_bwd(B, H, N, p_drop):
     bias = bias_saved
     delta = torch.zeros(B, H, N, device="cuda")
     dq_m = torch.zeros_like(qkv_m); dq_c = torch.zeros_like(qkv_m)
-    chunk = 2
-    slab = torch.zeros((B + chunk - 1) // chunk, H, 208, 208, device="cuda")
+    slab = torch.zeros(H, 208, 208, device="cuda")
+    ws = torch.empty(L.uvit_op_attn2_bwd_ws_bytes(B, H, N), dtype=torch.uint8, device="cuda")
     assert L.uvit_op_attn2_bwd(P(qkv_m), P(qkv_c), P(out_m), P(out_c), P(d_m), P(d_c), P(biasP), P(lse), P(delta), P(dq_m), P(dq_c),
-                               P(slab), 0, chunk, B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
+                               P(slab), 0, P(ws), B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
     close(dq_m, qm.grad, 5e-2, 2e-2 * qm.grad.abs().max().item(), "d qkv (mean stream)")
     close(dq_c, pc.grad, 5e-2, 2e-2 * pc.grad.abs().max().item(), "d qkv (cov stream, pre-ELU)")
-    close(slab.sum(0)[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
+    close(slab[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
 
 
 def dist_model(cfg):

@@ -47,3 +47,21 @@ if __name__ == "__main__":
                                                  P(ws), B, H, N, NP, 0.125, p, 1, 0, S())
             us = timeit(g)
             print(f"bwd  p={p} fused{' + dbias reduce' if with_dbias else '               '}: {us:7.1f} us  {2.5 * flops_fwd / us / 1e6:6.1f} TF/s (5 products)")
+
+    # ---- two-stream (Wasserstein) attention: forward, fused backward (+ bias-gradient reduction)
+    qkv_m = torch.randn(B * N, 3 * Cd, device="cuda").to(torch.bfloat16)
+    qkv_c = (torch.nn.functional.elu(torch.randn(B * N, 3 * Cd, device="cuda")) + 1).to(torch.bfloat16)
+    out_m = torch.zeros(B * N, Cd, device="cuda", dtype=torch.bfloat16); out_c = torch.zeros_like(out_m)
+    d_m = torch.randn(B * N, Cd, device="cuda").to(torch.bfloat16); d_c = torch.randn(B * N, Cd, device="cuda").to(torch.bfloat16)
+    dq_m = torch.zeros_like(qkv_m); dq_c = torch.zeros_like(qkv_m)
+    ws2 = torch.empty(L.uvit_op_attn2_bwd_ws_bytes(B, H, N), dtype=torch.uint8, device="cuda")
+    slab2 = torch.zeros(H, NP, NP, device="cuda")
+    for p in (0.0, 0.05):
+        f = lambda: L.uvit_op_attn2_fwd(P(qkv_m), P(qkv_c), P(biasP), P(out_m), P(out_c), P(lse), B, H, N, NP, 0.125, p, 1, 0, S())
+        us = timeit(f)
+        print(f"two-stream fwd  p={p}: {us:7.1f} us  {2.0 * flops_fwd / us / 1e6:6.1f} TF/s (4 products)")
+        for with_dbias in (True, False):
+            g = lambda: L.uvit_op_attn2_bwd(P(qkv_m), P(qkv_c), P(out_m), P(out_c), P(d_m), P(d_c), P(biasP), P(lse), P(delta), P(dq_m), P(dq_c),
+                                            P(slab2 if with_dbias else None), 1, P(ws2), B, H, N, NP, 0.125, p, 1, 0, S())
+            us = timeit(g)
+            print(f"two-stream bwd  p={p} fused{' + dbias reduce' if with_dbias else '               '}: {us:7.1f} us  {5.0 * flops_fwd / us / 1e6:6.1f} TF/s (10 products)")

@@ -257,126 +257,376 @@ __device__ __forceinline__ float back_cov(float dA, float dside, float y) {   //
 }
 
 // ------------------------------------------------------------------------------------------
-// backward, query-owned: dq, dcov_q (pre-ELU), delta, rel-pos-bias gradient over a batch chunk
+// backward, FUSED (round 4): every gradient of the two-stream attention from ONE recomputation of P.
+//
+// One 13-wave workgroup per (batch, head), the base kernel's structure (attention.hip, attn_bwd_fused_kernel) with the
+// Wasserstein score and its ten products.  Wave w owns the 16 queries 16 w .. 16 w + 15 ("query on the MFMA lane":
+// S^T = B.A^T with A = [m1 | sqrt c1] of the queries and B = [m2 | sqrt c2] of the keys) and the workgroup walks the keys in
+// steps of ONE 16-key tile.  Per step i:
+//   A_i (every wave): S^T (K = 128), dM.V^T, dC.CV^T of its queries against the step's key tile -> sigmoid(-W), P, PD, dS and
+//        gW = dL/dW in registers -> dA^T += B^T.gW^T straight from the accumulators (v_mfma_f32_16x16x16_bf16: the contraction is
+//        the step's 16 keys); PD, PD^2 and gW are written ONCE, as bf16, into the step buffers [208 queries][16 keys]; dS leaves
+//        for HBM from the registers (8 B per lane, 512 contiguous bytes per wave) for the relative-position-bias gradient;
+//   barrier;
+//   B_i (waves 0..7, in program order in front of A_{i+1}): the step's key-side gradients, contracted over ALL queries by
+//        transposed reads of the four query-side images and of the step buffers -- waves 0..3: dB_m, dB_c (one 16-feature tile
+//        each) and the column sum of gW (an all-ones A operand) from the gW buffer, waves 4..7: dV, dCV from PD / PD^2 -- then the
+//        chain rule back to the pre-sigmoid / pre-ELU inputs in fp32 and 8-B stores;
+//   waves 8..12 meanwhile fill the key ring: the step's 16 rows of k, cov_k are fetched TWO steps ahead into registers,
+//        transformed (sigmoid, sqrt sigmoid; the column term c_j on the way) and written one step ahead; v, cov_v by LDS-DMA.
+// Why steps of 16 keys: the B phase needs all four query-side operands whole (dM, dC, A_m, A_c: 104 KiB), and P, P^2, gW staged
+// for every query of a step; with 32-key steps (the base kernel's) that is 104 + 78 KiB + the key rows.  At 16 keys: 104 KiB +
+// 2 x 3 x 6.5 KiB of step buffers + 2 x 8 KiB of key rows = 159 KiB.
+// LDS images use the forward's swizzle (img_off2); step buffer rows are 32 B = four 8-B slots (4 keys each), slot s of row q
+// at s ^ ((q >> 2) & 3): the 8-B writes of a 16-lane group (16 consecutive rows, one slot) touch every bank once, and a
+// transposed read's 32-lane half covers 8 whole rows = 256 contiguous bytes.
 // ------------------------------------------------------------------------------------------
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(W2_WAVES * 64)
-void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ qkv_c, const bf16* __restrict__ o_m,
-                        const bf16* __restrict__ o_c, const bf16* __restrict__ d_m, const bf16* __restrict__ d_c,
-                        const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
-                        bf16* __restrict__ dqkv_m, bf16* __restrict__ dqkv_c, float* __restrict__ dbias_slab,
-                        int accumulate_slab, int B, int H, int N, int NP, int chunk, int nhalf, float scale,
-                        uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
+#define F2_WAVES 13
+#define F2_ROWS (NT_MAX * 16)                 // 208
+#define F2_IMG (F2_ROWS * 128)                // 26,624 B
+#define F2_SLOT (4 * 16 * 128)                // 8,192 B: Bm, Bc, V, CV rows of one 16-key step
+#define F2_SB (F2_ROWS * 32)                  // 6,656 B
+#define F2_LDS (4 * F2_IMG + 2 * F2_SLOT + 6 * F2_SB + 2 * 16 * 4)      // 162,944 B
+#define F2_BWAVES 8
+#ifndef F2_UNROLL
+#define F2_UNROLL 7
+#endif
+
+__device__ __forceinline__ int sb16_off(int q, int slot) { return q * 32 + ((slot ^ ((q >> 2) & 3)) << 3); }
+// B operand of the B phase (K = 32 queries): element j of lane (g, i) = buf[query (j<4 ? r_lo : r_hi) + 4g + (j&3)][key i]
+__device__ __forceinline__ bf16x8 sb16_col_frag(const char* sb, int r_lo, int r_hi, bool has_hi, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sb + sb16_off(r_lo + 4 * g + q, p)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, sb + sb16_off(r_hi + 4 * g + q, p)));
+    if (!has_hi) hi = s16x4{0, 0, 0, 0};
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// A operand of the K = 16 MFMA: lane (g, i) = img[row 4g + e][col0 + i], e = 0..3 (rows = the step's keys)
+__device__ __forceinline__ s16x4 col_frag16(const char* img, int col0, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + img_off2(4 * g + q, (col0 >> 3) + (p >> 1)) + ((p & 1) << 3)));
+}
+__device__ __forceinline__ void dma_rows8_2(char* img, int rb, const bf16* src, size_t stride, int row0, int n_valid, int lane) {
+    const int row = row0 + 8 * rb + (lane >> 3);
+    const int chunk = (lane & 7) ^ (lane >> 3);
+    const int r = row < n_valid ? row : n_valid - 1;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)r * stride + chunk * 8), LDS_PTR(void, img + rb * 1024), 16, 0, 0);
+}
+// one 16-B chunk of a token row through the transform: returns the transformed chunk and this chunk's part of the row term
+template <int TR>
+__device__ __forceinline__ bf16x8 tr_chunk(const bf16x8 v, float pre_scale, float& part) {
+    bf16x8 o;
+    part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = bf2f(v[j]);
+        if constexpr (TR == TR_SIG) { x = sigm(x * pre_scale); part += x * x; }
+        else { x = sigm(x); part += x; x = sqrtf(x); }
+        o[j] = f2bf(x);
+    }
+    return o;
+}
+
+template <bool HAS_BIAS, int NT_C>
+__global__ __launch_bounds__(F2_WAVES * 64)
+void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ qkv_c, const bf16* __restrict__ o_m,
+                            const bf16* __restrict__ o_c, const bf16* __restrict__ d_m, const bf16* __restrict__ d_c,
+                            const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
+                            bf16* __restrict__ dqkv_m, bf16* __restrict__ dqkv_c, uint2* __restrict__ ds_out, int H, int N, int NP,
+                            float scale, uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *bm = smem, *bc = smem + IMG_BYTES, *vimg = smem + 2 * IMG_BYTES, *cvimg = smem + 3 * IMG_BYTES;
-    float* cj = (float*)(smem + 4 * IMG_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* const qa = smem;                        // A_m: sigmoid(q * scale)
+    char* const qc = smem + F2_IMG;               // A_c: sqrt(sigmoid(cov_q))
+    char* const dmimg = smem + 2 * F2_IMG;
+    char* const dcimg = smem + 3 * F2_IMG;
+    char* const ring = smem + 4 * F2_IMG;         // 2 slots x {Bm, Bc, V, CV}[16 rows]
+    char* const sbuf = ring + 2 * F2_SLOT;        // 2 x {PD, PD^2, gW}
+    float* const cjr = (float*)(sbuf + 6 * F2_SB);  // 2 x 16 column terms
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int half = blockIdx.x % nhalf, hc = blockIdx.x / nhalf, h = hc % H, c = hc / H;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-    const int qt = half * W2_WAVES + wave;
-    const bool active = qt < nt;
-    const int q = qt * 16 + li;
-    const int qr = q < N ? q : N - 1;
-    float dbacc[NT_MAX][4];
-#pragma unroll
-    for (int t = 0; t < NT_MAX; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dbacc[t][r] = 0.f;
+    const int nt = NT_C ? NT_C : (N + 15) >> 4;
+    const bf16* base_m = qkv_m + (size_t)b * N * ld + h * HD;
+    const bf16* base_c = qkv_c + (size_t)b * N * ld + h * HD;
+    const bf16* dmbase = d_m + (size_t)b * N * C + h * HD;
+    const bf16* dcbase = d_c + (size_t)b * N * C + h * HD;
+    const bool active = NT_C ? true : wave < nt;
+    const int q = wave * 16 + li, qr = q < N ? q : N - 1;
 
-    for (int bi = 0; bi < chunk; ++bi) {
-        const int b = c * chunk + bi;
-        if (b >= B) break;
-        const int bh = b * H + h;
-        const bf16* base_m = qkv_m + (size_t)b * N * ld + h * HD;
-        const bf16* base_c = qkv_c + (size_t)b * N * ld + h * HD;
-        __syncthreads();
-        for (int i = tid; i < ROWS_PAD; i += W2_WAVES * 64) cj[i] = 0.f;
-        __syncthreads();
-        load_image_tr<TR_SIG>(bm, base_m + C, ld, N, 1.0f, cj, tid, W2_WAVES * 64);
-        load_image_tr<TR_SQRT_SIG>(bc, base_c + C, ld, N, 1.0f, cj, tid, W2_WAVES * 64);
-        load_image_tr<TR_NONE>(vimg, base_m + 2 * C, ld, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-        load_image_tr<TR_NONE>(cvimg, base_c + 2 * C, ld, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-        __syncthreads();
-        if (!active) continue;
-        const TokFrags A = load_tok(base_m + (size_t)qr * ld, base_c + (size_t)qr * ld, g, scale);
-        const float ri = gsum4(A.side);
+    // ---- dM, dC images by LDS-DMA (row blocks of 8; blocks beyond the last tile are never read)
+    for (int p = wave; p < 2 * (F2_ROWS / 8); p += F2_WAVES) {
+        const int img = p & 1, rb = p >> 1;
+        if (rb * 8 >= nt * 16) continue;
+        dma_rows8_2(img ? dcimg : dmimg, rb, img ? dcbase : dmbase, (size_t)C, 0, N, lane);
+    }
+    // ---- key ring loaders (waves 8..11): lane -> (tensor, row, chunk) of a step's 16 rows of k / cov_k
+    const int lw = wave - F2_BWAVES;                                   // 0..3 loaders of Bm / Bc, 4: the V / CV DMA
+    const int l_t = lane >> 5, l_row = 4 * (lw & 3) + ((lane >> 3) & 3), l_ch = lane & 7;
+    bf16x8 kraw = {};
+    auto k_fetch = [&](int step) {                                     // raw 16 B of key row 16 step + l_row
+        const int key = step * 16 + l_row;
+        const int kr = key < N ? key : N - 1;
+        kraw = *(const bf16x8*)((l_t ? base_c : base_m) + C + (size_t)kr * ld + l_ch * 8);
+    };
+    auto k_write = [&](int step) {                                     // transform -> ring slot, column term c_j
+        char* slot = ring + (step & 1) * F2_SLOT;
+        const int key = step * 16 + l_row;
+        float part;
+        bf16x8 o = l_t ? tr_chunk<TR_SQRT_SIG>(kraw, 1.0f, part) : tr_chunk<TR_SIG>(kraw, 1.0f, part);
+        if (key >= N) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+        }
+        *(bf16x8*)(slot + l_t * 2048 + img_off2(l_row, l_ch)) = o;
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+        part += __shfl_xor(part, 32, 64);
+        if ((lane & 39) == 0) cjr[(step & 1) * 16 + l_row] = part;
+    };
+    auto v_dma = [&](int step) {                                       // V, CV rows of the step: 4 pieces of 8 rows
+        char* slot = ring + (step & 1) * F2_SLOT;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+            dma_rows8_2(slot + 4096 + (pc >> 1) * 2048, pc & 1, ((pc >> 1) ? base_c : base_m) + 2 * C, ld, step * 16, N, lane);
+    };
+    if (lw >= 0 && lw < 4) { k_fetch(0); }
+    if (lw == 4) v_dma(0);
+
+    // ---- this wave's queries: A_m, A_c rows through the transform into the images (rows >= N zero), row term r_i,
+    //      delta = dM.mean + 2 dC.cov, LSE
+    float ri = 0.f, dl = 0.f, lse_q = 1e30f;        // padded query lanes: p = exp2(.. - 1e30) = 0
+    if (active) {
+        float side[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = wave * 16 + 8 * k + (lane >> 3), ch = lane & 7;
+            const int rr = row < N ? row : N - 1;
+            const bf16x8 vm = *(const bf16x8*)(base_m + (size_t)rr * ld + ch * 8);
+            const bf16x8 vc = *(const bf16x8*)(base_c + (size_t)rr * ld + ch * 8);
+            float pm_, pc_;
+            bf16x8 om_ = tr_chunk<TR_SIG>(vm, scale, pm_), oc_ = tr_chunk<TR_SQRT_SIG>(vc, 1.0f, pc_);
+            if (row >= N) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { om_[j] = f2bf(0.f); oc_[j] = f2bf(0.f); }
+            }
+            *(bf16x8*)(qa + img_off2(row, ch)) = om_;
+            *(bf16x8*)(qc + img_off2(row, ch)) = oc_;
+            float s_ = pm_ + pc_;
+            s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64);
+            side[k] = s_;                                              // row 8 k + (lane >> 3)
+        }
+        // lane (g, li) wants the row term of query li: rows 0..7 sit in side[0] of lanes 8 r, rows 8..15 in side[1]
+        const float s0 = __shfl(side[0], (li & 7) * 8, 64), s1 = __shfl(side[1], (li & 7) * 8, 64);
+        ri = li < 8 ? s0 : s1;
         const size_t orow = ((size_t)b * N + qr) * C + h * HD;
-        bf16x8 dmf[2], dcf[2];
-        float dl = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            dmf[kk] = *(const bf16x8*)(d_m + orow + kk * 32 + g * 8);
-            dcf[kk] = *(const bf16x8*)(d_c + orow + kk * 32 + g * 8);
-            const bf16x8 om = *(const bf16x8*)(o_m + orow + kk * 32 + g * 8), oc = *(const bf16x8*)(o_c + orow + kk * 32 + g * 8);
+            const bf16x8 dmf = *(const bf16x8*)(d_m + orow + kk * 32 + g * 8), dcf = *(const bf16x8*)(d_c + orow + kk * 32 + g * 8);
+            const bf16x8 omf = *(const bf16x8*)(o_m + orow + kk * 32 + g * 8), ocf = *(const bf16x8*)(o_c + orow + kk * 32 + g * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f(dmf[kk][j]) * bf2f(om[j]) + 2.0f * bf2f(dcf[kk][j]) * bf2f(oc[j]);
+            for (int j = 0; j < 8; ++j) dl += bf2f(dmf[j]) * bf2f(omf[j]) + 2.0f * bf2f(dcf[j]) * bf2f(ocf[j]);
         }
-        dl = gsum4(dl);                                   // delta_i = dM.mean + 2 dC.cov
-        const float lse_q = lse[(size_t)bh * N + qr];
-        if (g == 0 && q < N) delta[(size_t)bh * N + q] = dl;
-        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+        dl = gsum4(dl);
+        if (q < N) {
+            lse_q = lse[(size_t)bh * N + q];
+            if (g == 0) delta[(size_t)bh * N + q] = dl;
+        }
+    }
+    if (lw >= 0 && lw < 4) { k_write(0); if (1 < nt) k_fetch(1); }
+    float4 bnext;
+    auto bias_fetch = [&](int t, int lane) {
+        const int g = lane >> 4, q = wave * 16 + (lane & 15);
+        if constexpr (HAS_BIAS) {
+            const float* brow = biasP + ((size_t)h * NP + q) * NP + 4 * g;      // q < 208 <= NP
+            bnext = (t < nt && active) ? *(const float4*)(brow + t * 16) : make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG);
+        } else {
+            const int k0 = t * 16 + 4 * g;
+            bnext = make_float4(k0 < N ? 0.f : NEG_BIG, k0 + 1 < N ? 0.f : NEG_BIG, k0 + 2 < N ? 0.f : NEG_BIG, k0 + 3 < N ? 0.f : NEG_BIG);
+        }
+    };
+    bias_fetch(0, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
 
-        f32x4 dam[4], dac[4];
+    f32x4 dam[4], dac[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dam[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dac[dt] = dam[dt]; }
-        float dside = 0.f;
+    for (int dt = 0; dt < 4; ++dt) { dam[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dac[dt] = dam[dt]; }
+    float dside = 0.f;
+
+    // ================= A_i: this wave's 16 queries against the step's key tile
+    auto A_step = [&](int i, int lane) {
+        // per-lane offsets are re-derived from an opaque copy of the lane id every step: hoisted out of the loop they cost ~20 VGPRs
+        const int g = lane >> 4, li = lane & 15, q = wave * 16 + li;
+        const char* slot = ring + (i & 1) * F2_SLOT;
+        const char *bm = slot, *bc = slot + 2048, *vimg = slot + 4096, *cvimg = slot + 6144;
+        char* pbuf = sbuf + (i & 1) * 3 * F2_SB;
+        const float4 bcur = bnext;
+        if (i + 1 < nt) bias_fetch(i + 1, lane);
+        // the dropout draw comes BEFORE the MFMAs: no wave-uniform branch between an MFMA and the first VALU read of its result
+        // (hipcc pads the MFMA -> VALU wait states along the fall-through path only; attention.hip)
+        bool k4[4] = {true, true, true, true};
+        if (drop_thr) keep4b(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), i * 16 + 4 * g, drop_thr, k4);
+        const float4 cv4 = *(const float4*)(cjr + (i & 1) * 16 + 4 * g);
+        f32x4 sacc, pm, pc;
+        {
+            const bf16x8 k0 = rowf(bm, li, g), k1 = rowf(bm, li, 4 + g);
+            const bf16x8 a0 = rowf(qa, q, g), a1 = rowf(qa, q, 4 + g);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, a0, z, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, a1, sacc, 0, 0, 0);
+        }
+        {
+            const bf16x8 k0 = rowf(bc, li, g), k1 = rowf(bc, li, 4 + g);
+            const bf16x8 a0 = rowf(qc, q, g), a1 = rowf(qc, q, 4 + g);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, a0, sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, a1, sacc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const bf16x8 v0 = rowf(vimg, li, g), v1 = rowf(vimg, li, 4 + g);
+            const bf16x8 d0 = rowf(dmimg, q, g), d1 = rowf(dmimg, q, 4 + g);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, d0, z, 0, 0, 0);
+            pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, d1, pm, 0, 0, 0);
+        }
+        {
+            const bf16x8 v0 = rowf(cvimg, li, g), v1 = rowf(cvimg, li, 4 + g);
+            const bf16x8 d0 = rowf(dcimg, q, g), d1 = rowf(dcimg, q, 4 + g);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, d0, z, 0, 0, 0);
+            pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, d1, pc, 0, 0, 0);
+        }
+        const float bb[4] = {bcur.x, bcur.y, bcur.z, bcur.w};
+        const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
+        float pdv[4], p2v[4], gwv[4], dsv[4];
 #pragma unroll
-        for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
-            if (ks < nt2) {
-                float gw[2][4];
+        for (int r = 0; r < 4; ++r) {
+            const float sg = sigm(2.0f * sacc[r] - ri - cc[r]);                       // sigmoid(-W)
+            const float p = __builtin_amdgcn_exp2f(sg * LOG2E + bb[r] - lse_q);
+            const float pd = k4[r] ? p * inv_keep : 0.f;
+            // dPD = dM.v + 2 PD (dC.cv);  dP = D dPD;  dS = P (dP - delta);  dL/dW = -dS sg (1 - sg)
+            const float dpd = pm[r] + 2.0f * pd * pc[r];
+            const float ds = p * ((k4[r] ? dpd * inv_keep : 0.f) - dl);
+            const float gv = -ds * sg * (1.0f - sg);
+            pdv[r] = pd; p2v[r] = pd * pd; gwv[r] = gv; dsv[r] = ds;
+            dside += gv;
+        }
+        const bf16x4 pv = {f2bf(pdv[0]), f2bf(pdv[1]), f2bf(pdv[2]), f2bf(pdv[3])};
+        const bf16x4 p2 = {f2bf(p2v[0]), f2bf(p2v[1]), f2bf(p2v[2]), f2bf(p2v[3])};
+        const bf16x4 gw = {f2bf(gwv[0]), f2bf(gwv[1]), f2bf(gwv[2]), f2bf(gwv[3])};
+        *(bf16x4*)(pbuf + sb16_off(q, g)) = pv;
+        *(bf16x4*)(pbuf + F2_SB + sb16_off(q, g)) = p2;
+        *(bf16x4*)(pbuf + 2 * F2_SB + sb16_off(q, g)) = gw;
+        if (ds_out) {
+            const bf16x4 dv = {f2bf(dsv[0]), f2bf(dsv[1]), f2bf(dsv[2]), f2bf(dsv[3])};
+            ds_out[(((size_t)bh * nt + i) * nt + wave) * 64 + lane] = __builtin_bit_cast(uint2, dv);
+        }
+        const s16x4 gwf = __builtin_bit_cast(s16x4, gw);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int t = 2 * ks + tt;
+        for (int dt = 0; dt < 4; ++dt) {
+            dam[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(col_frag16(bm, dt * 16, lane), gwf, dam[dt], 0, 0, 0);
+            dac[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(col_frag16(bc, dt * 16, lane), gwf, dac[dt], 0, 0, 0);
+        }
+    };
+
+    // ================= B_i (waves 0..7): key-side gradients of the step's 16 keys, contracted over every query
+    const int role = wave >> 2, dtj = wave & 3;      // role 0: dB_m, dB_c, column sum of gW;  role 1: dV, dCV
+    auto B_step = [&](int i, int lane) {
+        const int g = lane >> 4, li = lane & 15;
+        const char* pbuf = sbuf + (i & 1) * 3 * F2_SB;
+        const int key = i * 16 + li;
+        const int kr = key < N ? key : N - 1;
+        // the raw inputs the chain rule needs, requested in front of the MFMA chain
+        const bf16* rm = base_m + (size_t)kr * ld + dtj * 16 + 4 * g;
+        const bf16* rc = base_c + (size_t)kr * ld + dtj * 16 + 4 * g;
+        bf16x4 x0, x1;
+        if (role == 0) { x0 = *(const bf16x4*)(rm + C); x1 = *(const bf16x4*)(rc + C); }
+        else { x0 = *(const bf16x4*)(rc + 2 * C); x1 = x0; }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+        const char* img0 = role == 0 ? qa : dmimg;
+        const char* img1 = role == 0 ? qc : dcimg;
+        const char* sb0 = role == 0 ? pbuf + 2 * F2_SB : pbuf;
+        const char* sb1 = role == 0 ? pbuf + 2 * F2_SB : pbuf + F2_SB;
+        const bf16 one = f2bf(1.0f);
+        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+        auto kstep = [&](int ks) {
+            const bool hk = 2 * ks + 1 < nt;
+            const int r_lo = 32 * ks, r_hi = hk ? r_lo + 16 : r_lo;
+            const bf16x8 a0 = colf(img0, r_lo, r_hi, dtj * 16, lane);
+            const bf16x8 a1 = colf(img1, r_lo, r_hi, dtj * 16, lane);
+            const bf16x8 b0 = sb16_col_frag(sb0, r_lo, r_hi, hk, lane);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
+            if (role == 0) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0, acc2, 0, 0, 0);
+            } else {
+                const bf16x8 b1 = sb16_col_frag(sb1, r_lo, r_hi, hk, lane);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+            }
+        };
+        if constexpr (NT_C != 0) {
+#pragma unroll F2_UNROLL
+            for (int ks = 0; ks < (NT_C + 1) / 2; ++ks) kstep(ks);
+        } else {
+            const int nk = (nt + 1) >> 1;
+            for (int ks = 0; ks < nk; ++ks) kstep(ks);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // loop exit / role branches: pad the MFMA -> VALU wait states by hand
+        // acc*[r] = gradient [key li][feature 16 dtj + 4 g + r]
+        if (key < N) {
+            bf16* om = dqkv_m + ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
+            bf16* oc = dqkv_c + ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
+            bf16x4 r0, r1;
+            if (role == 0) {
+                const float dsj = acc2[0];                    // d c_j = sum_i dL/dW_ij (every row of the all-ones product)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gw[tt][r] = 0.f;
-                    if (t < nt && t < NT_MAX) {
-                        f32x4 a = {0.f, 0.f, 0.f, 0.f}, pm = {0.f, 0.f, 0.f, 0.f}, pc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bm, t * 16 + li, kk * 4 + g), A.m[kk], a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bc, t * 16 + li, kk * 4 + g), A.c[kk], a, 0, 0, 0);
-                            pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(vimg, t * 16 + li, kk * 4 + g), dmf[kk], pm, 0, 0, 0);
-                            pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(cvimg, t * 16 + li, kk * 4 + g), dcf[kk], pc, 0, 0, 0);
-                        }
-                        const float4 cv4 = *(const float4*)(cj + t * 16 + 4 * g);
-                        const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
-                        float bb[4];
-                        if constexpr (HAS_BIAS) {
-                            const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                            bb[0] = bv.x; bb[1] = bv.y; bb[2] = bv.z; bb[3] = bv.w;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
-                        }
-                        bool k4[4] = {true, true, true, true};
-                        if (drop_thr) keep4b(drop_key, rowpair, t * 16 + 4 * g, drop_thr, k4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float sg = sigm(2.0f * a[r] - ri - cc[r]);
-                            const float p = __builtin_amdgcn_exp2f(sg * LOG2E + bb[r] - lse_q);
-                            const float pd = k4[r] ? p * inv_keep : 0.f;
-                            // dPD = dM.v + 2 PD (dC.cv);  dP = D dPD;  ds = P (dP - delta)
-                            const float dpd = pm[r] + 2.0f * pd * pc[r];
-                            const float ds = p * ((k4[r] ? dpd * inv_keep : 0.f) - dl);
-                            dbacc[t < NT_MAX ? t : 0][r] += ds;
-                            const float gv = -ds * sg * (1.0f - sg);                  // dL/dW
-                            gw[tt][r] = gv;
-                            dside += gv;
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    r0[r] = f2bf(back_mean(-2.0f * acc0[r], dsj, bf2f(x0[r]), 1.0f));
+                    r1[r] = f2bf(back_cov(-2.0f * acc1[r], dsj, bf2f(x1[r])));
                 }
-                const bf16x8 gf = pk8(gw[0], gw[1]);
+                *(bf16x4*)(om + C) = r0;
+                *(bf16x4*)(oc + C) = r1;
+            } else {
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    dam[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(bm, 2 * ks * 16, (2 * ks + 1) * 16, dt * 16, lane), gf, dam[dt], 0, 0, 0);
-                    dac[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(bc, 2 * ks * 16, (2 * ks + 1) * 16, dt * 16, lane), gf, dac[dt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    r0[r] = f2bf(acc0[r]);
+                    r1[r] = f2bf(acc1[r] * fminf(bf2f(x0[r]), 1.0f));                // ELU' of the cov_v pre-activation
                 }
+                *(bf16x4*)(om + 2 * C) = r0;
+                *(bf16x4*)(oc + 2 * C) = r1;
             }
         }
-        dside = gsum4(dside);                              // d r_i = sum_j dL/dW_ij
+    };
+
+    // iteration i: B_{i-1} / the ring fill for step i + 1, then A_i, then the step's barrier
+#pragma unroll 1
+    for (int i = 0; i <= nt; ++i) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (wave < F2_BWAVES) {
+            if (i > 0) B_step(i - 1, ln);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nt && active) A_step(i, ln);
+        } else {
+            if (lw < 4) {
+                if (i + 1 < nt) k_write(i + 1);
+                if (i + 2 < nt) k_fetch(i + 2);
+            } else if (i + 1 < nt) {
+                v_dma(i + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < nt && active) A_step(i, ln);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (active) {
+        dside = gsum4(dside);                                  // d r_i = sum_j dL/dW_ij
         if (q < N) {
             const bf16* xm = base_m + (size_t)q * ld + 4 * g;
             const bf16* xc = base_c + (size_t)q * ld + 4 * g;
@@ -387,7 +637,7 @@ void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__
                 const bf16x4 vm = *(const bf16x4*)(xm + dt * 16), vc = *(const bf16x4*)(xc + dt * 16);
                 bf16x4 rm, rc;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {       // dA = -2 sum_j g B_j
+                for (int r = 0; r < 4; ++r) {       // dA = -2 sum_j gW B_j
                     rm[r] = f2bf(back_mean(-2.0f * dam[dt][r], dside, bf2f(vm[r]), scale));
                     rc[r] = f2bf(back_cov(-2.0f * dac[dt][r], dside, bf2f(vc[r])));
                 }
@@ -396,138 +646,41 @@ void attn2_bwd_q_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__
             }
         }
     }
-    if (dbias_slab && active) {
-        float* slab = dbias_slab + ((size_t)(c * H + h) * NP) * NP;
-#pragma unroll
-        for (int t = 0; t < NT_MAX; ++t)
-            if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* p = slab + (size_t)(t * 16 + 4 * g + r) * NP + q;
-                    *p = accumulate_slab ? *p + dbacc[t][r] : dbacc[t][r];
-                }
-            }
-    }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward, key-owned: dk, dcov_k, dv, dcov_v (cov parts pre-ELU)
-// ------------------------------------------------------------------------------------------
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(W2_WAVES * 64)
-void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ qkv_c, const bf16* __restrict__ d_m,
-                         const bf16* __restrict__ d_c, const float* __restrict__ biasP, const float* __restrict__ lse,
-                         const float* __restrict__ delta, bf16* __restrict__ dqkv_m, bf16* __restrict__ dqkv_c, int H,
-                         int N, int NP, int nhalf, float scale, uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *am = smem, *ac = smem + IMG_BYTES, *dmimg = smem + 2 * IMG_BYTES, *dcimg = smem + 3 * IMG_BYTES;
-    float* ri_s = (float*)(smem + 4 * IMG_BYTES);
-    float* lse_s = ri_s + ROWS_PAD;
-    float* dl_s = lse_s + ROWS_PAD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, li = lane & 15;
-    const int half = blockIdx.x % nhalf, bh = blockIdx.x / nhalf, b = bh / H, h = bh - b * H;
-    const int C = H * HD;
-    const size_t ld = 3 * (size_t)C;
-    const bf16* base_m = qkv_m + (size_t)b * N * ld + h * HD;
-    const bf16* base_c = qkv_c + (size_t)b * N * ld + h * HD;
-    for (int i = tid; i < ROWS_PAD; i += W2_WAVES * 64) {
-        ri_s[i] = 0.f;
-        lse_s[i] = i < N ? lse[(size_t)bh * N + i] : 0.f;
-        dl_s[i] = i < N ? delta[(size_t)bh * N + i] : 0.f;
+// Bias gradient from the dS tiles the fused kernel streamed out: slab[h][key][q] += sum_b dS_b[h][q][key].
+// ds = [B * H][nt key tiles][nt query tiles][64 lanes] x 8 B: lane (g, li) of tile (t, w) holds dS[q = 16 w + li][keys 16 t + 4 g ..+3].
+// One 256-thread workgroup per (head, key tile, 4 query tiles, batch part): wave k streams tile (t, 4 wq + k) of every sample of the
+// part (512 contiguous bytes per wave and sample), the [16 keys][64 q] partial tile is turned through LDS and added with one fp32
+// atomic per lane, 256 contiguous bytes per wave-instruction.
+#define DBR2_PARTS 4
+__global__ __launch_bounds__(256)
+void attn2_dbias_reduce_kernel(const uint2* __restrict__ ds, float* __restrict__ slab, int B, int H, int N, int NP) {
+    __shared__ float tile[16][65];
+    const int nt = (N + 15) >> 4, nq4 = (nt + 3) >> 2;
+    const int wq = blockIdx.x % nq4, ht = blockIdx.x / nq4, t = ht % nt, h = ht / nt;
+    const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int w = 4 * wq + k;
+    const int per = (B + DBR2_PARTS - 1) / DBR2_PARTS, b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w < nt) {
+        const uint2* p = ds + (((size_t)h * nt + t) * nt + w) * 64 + lane;
+        const size_t bstride = (size_t)H * nt * nt * 64;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) {
+            const bf16x4 v = __builtin_bit_cast(bf16x4, p[b * bstride]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += bf2f(v[j]);
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[4 * g + j][16 * k + li] = acc[j];
     __syncthreads();
-    load_image_tr<TR_SIG>(am, base_m, ld, N, scale, ri_s, tid, W2_WAVES * 64);
-    load_image_tr<TR_SQRT_SIG>(ac, base_c, ld, N, 1.0f, ri_s, tid, W2_WAVES * 64);
-    load_image_tr<TR_NONE>(dmimg, d_m + (size_t)b * N * C + h * HD, C, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-    load_image_tr<TR_NONE>(dcimg, d_c + (size_t)b * N * C + h * HD, C, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-    __syncthreads();
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
-    const int kt = half * W2_WAVES + wave;
-    if (kt >= nt) return;
-    const int key = kt * 16 + li;
-    const int kr = key < N ? key : N - 1;
-    const TokFrags Bf = load_tok(base_m + C + (size_t)kr * ld, base_c + C + (size_t)kr * ld, g, 1.0f);
-    const float cjv = key < N ? gsum4(Bf.side) : gsum4(Bf.side);
-    bf16x8 vf[2], cvf[2];
+    const int qo = 64 * wq + lane;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        vf[kk] = *(const bf16x8*)(base_m + 2 * C + (size_t)kr * ld + kk * 32 + g * 8);
-        cvf[kk] = *(const bf16x8*)(base_c + 2 * C + (size_t)kr * ld + kk * 32 + g * 8);
-    }
-    f32x4 dbm[4], dbc[4], dv[4], dcv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dbm[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dbc[dt] = dbm[dt]; dv[dt] = dbm[dt]; dcv[dt] = dbm[dt]; }
-    float dside = 0.f;
-
-#pragma unroll 1
-    for (int qs = 0; qs < nt2; ++qs) {
-        float pdv[2][4], pd2[2][4], gw[2][4];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int qt = 2 * qs + tt;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pdv[tt][r] = 0.f; pd2[tt][r] = 0.f; gw[tt][r] = 0.f; }
-            if (qt < nt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f}, pm = {0.f, 0.f, 0.f, 0.f}, pc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(am, qt * 16 + li, kk * 4 + g), Bf.m[kk], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(ac, qt * 16 + li, kk * 4 + g), Bf.c[kk], a, 0, 0, 0);
-                    pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(dmimg, qt * 16 + li, kk * 4 + g), vf[kk], pm, 0, 0, 0);
-                    pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(dcimg, qt * 16 + li, kk * 4 + g), cvf[kk], pc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // padded query rows: zero A / dM / dC / delta / lse rows and a zero bias row -> finite p, zero gradients
-                    const int q = qt * 16 + 4 * g + r;
-                    float bv;
-                    if constexpr (HAS_BIAS) bv = biasP[((size_t)h * NP + q) * NP + key]; else bv = key < N ? 0.f : NEG_BIG;
-                    const float sg = sigm(2.0f * a[r] - ri_s[q] - cjv);
-                    const float p = __builtin_amdgcn_exp2f(sg * LOG2E + bv - lse_s[q]);
-                    bool kp = true;
-                    if (drop_thr) kp = keep1b(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), key, drop_thr);
-                    const float pd = kp ? p * inv_keep : 0.f;
-                    const float dpd = pm[r] + 2.0f * pd * pc[r];
-                    const float ds = p * ((kp ? dpd * inv_keep : 0.f) - dl_s[q]);
-                    const float gv = q < N ? -ds * sg * (1.0f - sg) : 0.f;
-                    pdv[tt][r] = pd; pd2[tt][r] = pd * pd; gw[tt][r] = gv;
-                    dside += gv;
-                }
-            }
-        }
-        const bf16x8 pf = pk8(pdv[0], pdv[1]), pf2 = pk8(pd2[0], pd2[1]), gf = pk8(gw[0], gw[1]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(dmimg, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane), pf, dv[dt], 0, 0, 0);
-            dcv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(dcimg, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane), pf2, dcv[dt], 0, 0, 0);
-            dbm[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(am, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane), gf, dbm[dt], 0, 0, 0);
-            dbc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(ac, 2 * qs * 16, (2 * qs + 1) * 16, dt * 16, lane), gf, dbc[dt], 0, 0, 0);
-        }
-    }
-    dside = gsum4(dside);                                  // d c_j = sum_i dL/dW_ij
-    if (key < N) {
-        const bf16* xk = base_m + C + (size_t)key * ld + 4 * g;
-        const bf16* xck = base_c + C + (size_t)key * ld + 4 * g;
-        const bf16* xcv = base_c + 2 * C + (size_t)key * ld + 4 * g;
-        bf16* om = dqkv_m + ((size_t)b * N + key) * ld + h * HD + 4 * g;
-        bf16* oc = dqkv_c + ((size_t)b * N + key) * ld + h * HD + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16x4 vk = *(const bf16x4*)(xk + dt * 16), vck = *(const bf16x4*)(xck + dt * 16), vcv = *(const bf16x4*)(xcv + dt * 16);
-            bf16x4 rk, rck, rv, rcv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rk[r] = f2bf(back_mean(-2.0f * dbm[dt][r], dside, bf2f(vk[r]), 1.0f));
-                rck[r] = f2bf(back_cov(-2.0f * dbc[dt][r], dside, bf2f(vck[r])));
-                rv[r] = f2bf(dv[dt][r]);
-                rcv[r] = f2bf(dcv[dt][r] * fminf(bf2f(vcv[r]), 1.0f));           // ELU' of the cov_v pre-activation
-            }
-            *(bf16x4*)(om + C + dt * 16) = rk;
-            *(bf16x4*)(om + 2 * C + dt * 16) = rv;
-            *(bf16x4*)(oc + C + dt * 16) = rck;
-            *(bf16x4*)(oc + 2 * C + dt * 16) = rcv;
-        }
+    for (int j = 0; j < 4; ++j) {
+        const int key = 16 * t + 4 * k + j;
+        if (key < N && qo < N) atomicAdd(slab + ((size_t)h * NP + key) * NP + qo, tile[4 * k + j][lane]);
     }
 }
 
@@ -535,13 +688,12 @@ void attn2_bwd_kv_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict_
 // launchers
 // ------------------------------------------------------------------------------------------
 #define FWD2_LDS (4 * IMG_BYTES + ROWS_PAD * 4)
-#define BKV2_LDS (4 * IMG_BYTES + 3 * ROWS_PAD * 4)
 static std::once_flag g_attr2_once;
 static void init2_impl() {
 #define SETA(K, B) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B)
     SETA(attn2_fwd_kernel<true>, FWD2_LDS); SETA(attn2_fwd_kernel<false>, FWD2_LDS);
-    SETA(attn2_bwd_q_kernel<true>, FWD2_LDS); SETA(attn2_bwd_q_kernel<false>, FWD2_LDS);
-    SETA(attn2_bwd_kv_kernel<true>, BKV2_LDS); SETA(attn2_bwd_kv_kernel<false>, BKV2_LDS);
+    SETA((attn2_bwd_fused_kernel<true, 0>), F2_LDS); SETA((attn2_bwd_fused_kernel<false, 0>), F2_LDS);
+    SETA((attn2_bwd_fused_kernel<true, NT_MAX>), F2_LDS); SETA((attn2_bwd_fused_kernel<false, NT_MAX>), F2_LDS);
 #undef SETA
 }
 static void init2() { std::call_once(g_attr2_once, init2_impl); }
@@ -559,26 +711,39 @@ int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* bia
     return uvit_check_launch();
 }
 
+size_t uvit_attn2_bwd_ws_bytes(int B, int H, int N) {
+    const size_t nt = (size_t)(N + 15) / 16;
+    return (size_t)B * H * nt * nt * 512;
+}
+
+// ds_ws: uvit_attn2_bwd_ws_bytes(B, H, N) bytes of bf16 dS tiles, written when want_ds != 0 (the bias gradient needs them)
 int uvit_attn2_bwd_launch(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
-                          const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* dbias_slab,
-                          int accumulate_slab, int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
-                          uint32_t layer, hipStream_t s) {
-    if (B <= 0 || H <= 0 || N <= 0 || N > NT_MAX * 16 || chunk <= 0) return UVIT_ERR_SHAPE;
+                          const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, void* ds_ws, int want_ds,
+                          int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
+    if (B <= 0 || H <= 0 || N <= 0 || N > NT_MAX * 16) return UVIT_ERR_SHAPE;
+    if (NP < NT_MAX * 16 || (NP & 3) || (want_ds && !ds_ws)) return UVIT_ERR_ARG;
     init2();
     const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t key = uvit_layer_key(seed, layer);
-    const int nt = (N + 15) / 16, nhalf = nt > W2_WAVES ? 2 : 1;
-    const int nchunk = (B + chunk - 1) / chunk;
-#define QA dim3(H * nchunk * nhalf), dim3(W2_WAVES * 64), FWD2_LDS, s, (const bf16*)qkv_m, (const bf16*)qkv_c, (const bf16*)o_m, \
-        (const bf16*)o_c, (const bf16*)d_m, (const bf16*)d_c, biasP, lse, delta, (bf16*)dqkv_m, (bf16*)dqkv_c, dbias_slab, accumulate_slab, \
-        B, H, N, NP, chunk, nhalf, scale, thr, inv_keep, key
-    if (biasP) hipLaunchKernelGGL(attn2_bwd_q_kernel<true>, QA); else hipLaunchKernelGGL(attn2_bwd_q_kernel<false>, QA);
-#undef QA
-    int rc = uvit_check_launch(); if (rc) return rc;
-#define KA dim3(B * H * nhalf), dim3(W2_WAVES * 64), BKV2_LDS, s, (const bf16*)qkv_m, (const bf16*)qkv_c, (const bf16*)d_m, \
-        (const bf16*)d_c, biasP, lse, delta, (bf16*)dqkv_m, (bf16*)dqkv_c, H, N, NP, nhalf, scale, thr, inv_keep, key
-    if (biasP) hipLaunchKernelGGL(attn2_bwd_kv_kernel<true>, KA); else hipLaunchKernelGGL(attn2_bwd_kv_kernel<false>, KA);
-#undef KA
+    uint2* dsw = want_ds ? (uint2*)ds_ws : nullptr;
+#define BA dim3(B * H), dim3(F2_WAVES * 64), F2_LDS, s, (const bf16*)qkv_m, (const bf16*)qkv_c, (const bf16*)o_m, (const bf16*)o_c, \
+        (const bf16*)d_m, (const bf16*)d_c, biasP, lse, delta, (bf16*)dqkv_m, (bf16*)dqkv_c, dsw, H, N, NP, scale, thr, inv_keep, key
+    if ((N + 15) / 16 == NT_MAX) {
+        if (biasP) hipLaunchKernelGGL((attn2_bwd_fused_kernel<true, NT_MAX>), BA); else hipLaunchKernelGGL((attn2_bwd_fused_kernel<false, NT_MAX>), BA);
+    } else {
+        if (biasP) hipLaunchKernelGGL((attn2_bwd_fused_kernel<true, 0>), BA); else hipLaunchKernelGGL((attn2_bwd_fused_kernel<false, 0>), BA);
+    }
+#undef BA
+    return uvit_check_launch();
+}
+
+// dbias_slab = ONE [H][NP][NP] slab laid out [h][key][q]; accumulate = 0 overwrites it (zero fill first), 1 adds
+int uvit_attn2_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accumulate, int B, int H, int N, int NP, hipStream_t s) {
+    if (B <= 0 || H <= 0 || N <= 0 || N > NT_MAX * 16) return UVIT_ERR_SHAPE;
+    if (!ds_ws || !dbias_slab || NP < NT_MAX * 16) return UVIT_ERR_ARG;
+    if (!accumulate) { int rc = uvit_zero_launch(dbias_slab, (size_t)H * NP * NP * sizeof(float), s); if (rc) return rc; }
+    const int nt = (N + 15) / 16, nq4 = (nt + 3) / 4;
+    hipLaunchKernelGGL(attn2_dbias_reduce_kernel, dim3(H * nt * nq4, DBR2_PARTS), dim3(256), 0, s, (const uint2*)ds_ws, dbias_slab, B, H, N, NP);
     return uvit_check_launch();
 }

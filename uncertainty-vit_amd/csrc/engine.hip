@@ -218,10 +218,11 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     }
     const size_t bias_n = (size_t)e->H * e->NP * e->NP;
     e->biasP_s = b.take<float>(bias_n); e->biasP_t = b.take<float>(bias_n);
-    e->slabs = b.take<float>(bias_n * e->nchunk);
+    e->slabs = b.take<float>(bias_n);       // ONE bias-gradient slab [h][key][q] (both model families since round 4)
     e->delta = b.take<float>((size_t)e->B * e->H * e->N);
-    if (e->S == 1 && e->cfg.use_shared_rel_pos_bias)
-        for (int k = 0; k < 2; ++k) e->ds_ws[k] = b.take<char>(uvit_attn_bwd_fused_ws_bytes(e->B, e->H, e->N));
+    if (e->cfg.use_shared_rel_pos_bias)
+        for (int k = 0; k < 2; ++k)
+            e->ds_ws[k] = b.take<char>(e->S == 1 ? uvit_attn_bwd_fused_ws_bytes(e->B, e->H, e->N) : uvit_attn2_bwd_ws_bytes(e->B, e->H, e->N));
     e->dXa = b.take<float>(Mp * C); e->dXb = b.take<float>(Mp * C);
     for (int k = 0; k < 2; ++k) {
         e->dY1[k] = b.take<bf16>(Mp * C); e->dY2[k] = b.take<bf16>(Mp * C); e->dH[k] = b.take<bf16>(Mp * Hd);
@@ -820,21 +821,24 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     const float* biasP = e->biasP_s;
     float* slabs = e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr;
-    if (S == 1) {
-        // fused backward: dQ, dK, dV from one recomputation of P; dS (bf16) goes to the parity buffer and its batch reduction into
-        // the ONE bias-gradient slab runs on the second stream, beside the dgrad chain.  The parity buffer of layer l was last read
-        // by the reduction of layer l + 2, which precedes ev_wdone[l + 2] on that stream (waited for above).
+    {
+        // fused backward (both model families): every gradient from one recomputation of P; dS (bf16) goes to the parity buffer and
+        // its batch reduction into the ONE bias-gradient slab runs on the second stream, beside the dgrad chain.  The parity buffer
+        // of layer l was last read by the reduction of layer l + 2, which precedes ev_wdone[l + 2] on that stream (waited for above).
         void* dsw = slabs ? e->ds_ws[par] : nullptr;
-        CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP,
-                                         0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+        if (S == 1) {
+            CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP,
+                                             0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+        } else {
+            CHECK(uvit_attn2_bwd_launch(a.qkv, a.qkv + Mp * 3 * C, a.attn, a.attn + Mp * C, e->dAttn, e->dAttn + Mp * C, biasP, a.lse,
+                                        e->delta, dqkv, dqkv + Mp * 3 * C, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP, 0.125f, pdrop,
+                                        e->last_seed, (uint32_t)l, s));
+        }
         if (dsw) {
             if (e->dual) { HIPCHECK(hipEventRecord(e->ev_ds, s)); HIPCHECK(hipStreamWaitEvent(ws, e->ev_ds, 0)); }
-            CHECK(uvit_attn_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
+            if (S == 1) CHECK(uvit_attn_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
+            else CHECK(uvit_attn2_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
         }
-    } else {
-        CHECK(uvit_attn2_bwd_launch(a.qkv, a.qkv + Mp * 3 * C, a.attn, a.attn + Mp * C, e->dAttn, e->dAttn + Mp * C, biasP, a.lse,
-                                    e->delta, dqkv, dqkv + Mp * 3 * C, slabs, e->slab_started ? 1 : 0, e->chunk, e->B, e->H, e->N,
-                                    e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s));
     }
     e->slab_started = true;
     CHECK(handoff(3));
@@ -881,7 +885,7 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     if (e->cfg.use_abs_pos_emb) CHECK(uvit_pos_bwd_launch(e->dXa, g + lo.pos, e->B, e->N, C, s));     // d pos_embed = sum_b dX[b]
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum / bias-gradient reduction has landed
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
-        CHECK(uvit_relpos_scatter_launch(e->slabs, e->S == 1 ? 1 : e->nchunk, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
+        CHECK(uvit_relpos_scatter_launch(e->slabs, 1, e->buf.rel_index, g + lo.relt, e->H, e->N, e->NP, s));
     // fold the replicated column-sum accumulators into the no-decay gradients
     CHECK(uvit_reduce_replicas_launch(e->grep, g + lo.n_decay, e->n_nd, NREP, e->n_nd, s));
     CHECK(uvit_poison_if_nonfinite_launch(e->loss, g + lo.n_decay, e->poisoned, s));     // non-finite loss -> every rank's norm is NaN
@@ -1002,13 +1006,19 @@ extern "C" int uvit_op_attn2_fwd(const void* qkv_m, const void* qkv_c, const flo
     if (!qkv_m || !qkv_c || !out_m || !out_c || !lse) return UVIT_ERR_ARG;
     return uvit_attn2_fwd_launch(qkv_m, qkv_c, biasP, out_m, out_c, lse, B, H, N, NP, scale, p_drop, seed, layer, S(st));
 }
+extern "C" int64_t uvit_op_attn2_bwd_ws_bytes(int B, int H, int N) {
+    if (B <= 0 || H <= 0 || N <= 0) return UVIT_ERR_SHAPE;
+    return (int64_t)uvit_attn2_bwd_ws_bytes(B, H, N);
+}
 extern "C" int uvit_op_attn2_bwd(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
                                  const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* slab, int acc,
-                                 int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer,
+                                 void* ds_ws, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer,
                                  uvit_stream st) {
-    if (!qkv_m || !qkv_c || !o_m || !o_c || !d_m || !d_c || !lse || !delta || !dqkv_m || !dqkv_c) return UVIT_ERR_ARG;
-    return uvit_attn2_bwd_launch(qkv_m, qkv_c, o_m, o_c, d_m, d_c, biasP, lse, delta, dqkv_m, dqkv_c, slab, acc, chunk, B, H, N, NP,
-                                 scale, p_drop, seed, layer, S(st));
+    if (!qkv_m || !qkv_c || !o_m || !o_c || !d_m || !d_c || !lse || !delta || !dqkv_m || !dqkv_c || (slab && !ds_ws)) return UVIT_ERR_ARG;
+    CHECK(uvit_attn2_bwd_launch(qkv_m, qkv_c, o_m, o_c, d_m, d_c, biasP, lse, delta, dqkv_m, dqkv_c, ds_ws, slab != nullptr, B, H, N, NP,
+                                scale, p_drop, seed, layer, S(st)));
+    if (slab) CHECK(uvit_attn2_dbias_reduce_launch(ds_ws, slab, acc, B, H, N, NP, S(st)));
+    return UVIT_OK;
 }
 extern "C" int uvit_op_relpos_gather(const float* t, const int32_t* idx, float* biasP, int H, int N, int NP, uvit_stream st) {
     return uvit_relpos_gather_launch(t, idx, biasP, H, N, NP, S(st));

@@ -80,10 +80,13 @@ int uvit_attn_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accu
 // attention2.hip (two-stream Wasserstein attention)
 int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse,
                           int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+// fused backward (round 4; same contract as the base model's): dS tiles (bf16) go to ds_ws when want_ds != 0 and
+// uvit_attn2_dbias_reduce_launch sums them over the batch into ONE [H][NP][NP] slab laid out [h][key][q]
+size_t uvit_attn2_bwd_ws_bytes(int B, int H, int N);
 int uvit_attn2_bwd_launch(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
-                          const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, float* dbias_slab,
-                          int accumulate_slab, int chunk, int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed,
-                          uint32_t layer, hipStream_t s);
+                          const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, void* ds_ws, int want_ds,
+                          int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+int uvit_attn2_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accumulate, int B, int H, int N, int NP, hipStream_t s);
 
 // norm.hip
 int uvit_ln_fwd_launch(const float* x, const float* w, const float* b, void* y_bf16, float* mean, float* rstd,

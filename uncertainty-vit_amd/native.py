@@ -122,7 +122,8 @@ _PROTOTYPES = {
     "uvit_op_attn_bwd_ws_bytes": (_i64, [_i, _i, _i]),
     "uvit_op_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_attn2_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
-    "uvit_op_attn2_bwd": (_i, [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
+    "uvit_op_attn2_bwd_ws_bytes": (_i64, [_i, _i, _i]),
+    "uvit_op_attn2_bwd": (_i, [_vp] * 12 + [_i, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
     "uvit_op_relpos_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "uvit_op_relpos_scatter": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "uvit_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
