@@ -223,6 +223,8 @@ def main():
                          gp_layer=False, gumbel_softmax=False, sinkformer=False, h_sto_trans=False).to(dev)
     model.train()
     ema = utils.ModelEmaV2(model, decay=0.9998)
+    if world > 1:
+        utils.broadcast_model_state(model, ema, src=0)     # DDP's constructor broadcast (run_cyclical.py:516)
 
     class A:
         opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)

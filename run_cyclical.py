@@ -234,6 +234,8 @@ def main(args):
 
     utils.auto_load_model(args=args, model=model, model_without_ddp=model_without_ddp, optimizer=optimizer,
                           loss_scaler=loss_scaler, model_ema=model_ema)
+    # DDP's constructor broadcast (run_cyclical.py:516): every rank continues from rank 0's weights, EMA and optimizer moments
+    utils.broadcast_model_state(model_without_ddp, model_ema, optimizer, src=0)
     target_layers = literal_eval(args.target_layers)
     assert len(target_layers) > 0
     print(f"target layers: {target_layers}")

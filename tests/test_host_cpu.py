@@ -230,6 +230,15 @@ hp = make_step_params([1], ArenaAdamW(m, 1e-3, 0.05), 3.0, 2.0, False, -1, True,
 assert abs(hp.grad_scale - 0.5) < 1e-9          # SUM all-reduce then 1/world == DDP's mean
 sv = utils.SmoothedValue(); sv.update(float(rank + 1)); sv.synchronize_between_processes()
 assert sv.count == 2 and sv.total == 3.0
+# DDP's constructor broadcast (run_cyclical.py:516): ranks that start from different weights / EMA / moments continue from rank 0's
+m2 = tiny_model(); ema2 = utils.ModelEmaV2(m2, decay=0.5); opt2 = ArenaAdamW(m2, 1e-3, 0.05); opt2._ensure_state()
+with torch.no_grad():
+    m2._arena.fill_(float(rank + 1)); ema2.module._arena.fill_(10.0 * (rank + 1)); opt2.exp_avg.fill_(100.0 * (rank + 1)); opt2.exp_avg_sq.fill_(7.0 + rank)
+m2._shadows_stale = False
+assert utils.broadcast_model_state(m2, ema2, opt2, src=0) == 4
+assert torch.all(m2._arena == 1.0) and torch.all(ema2.module._arena == 10.0) and torch.all(opt2.exp_avg == 100.0) and torch.all(opt2.exp_avg_sq == 7.0)
+assert m2._shadows_stale, "the bf16 shadows must be rebuilt after the broadcast"
+assert all(torch.all(p == 1.0) for p in m2.parameters()), "the nn.Parameters are views of the arena"
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -440,3 +449,20 @@ def test_optimizer_state_dict_interchanges_with_torch_adamw(native):
             assert torch.equal(ref2.state_dict()["state"][i][k], tsd["state"][i][k])
         assert float(ref2.state_dict()["state"][i]["step"]) == 2.0
     assert ArenaAdamW(tiny_model(), 1e-3, 0.05).state_dict()["state"] == {}      # nothing stepped yet: empty, as in torch
+
+
+def test_mfma_hazard_guard_flags_the_broken_stream_and_passes_the_tree():
+    """tools/check_mfma_hazard.py (run by build.sh): the hand-written broken stream and the hipcc-compiled micro kernel with a
+    wave-uniform branch between an MFMA and the read of its result are flagged; the attention kernels of the tree are clean."""
+    tool = os.path.join(ROOT, "tools", "check_mfma_hazard.py")
+    assert subprocess.run([sys.executable, tool, "--self-test"], capture_output=True, text=True).returncode == 0
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    r = subprocess.run([sys.executable, tool, "--compile", os.path.join(ROOT, "tools", "micro", "mfma_branch_hazard.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "taken branch" in r.stdout, r.stdout + r.stderr
+    csrc = os.path.join(ROOT, "uncertainty-vit_amd", "csrc")
+    r = subprocess.run([sys.executable, tool, "--compile", os.path.join(csrc, "attention.hip"), os.path.join(csrc, "attention2.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -20,6 +20,13 @@
 #include "common.h"
 #include "uvit_internal.h"
 
+// hand-placed MFMA -> VALU wait states where a branch follows an MFMA chain (tools/check_mfma_hazard.py is the build-time guard;
+// -DATTN_NO_HAZARD_PAD builds the deliberately broken variant the guard must flag)
+#ifdef ATTN_NO_HAZARD_PAD
+#define HAZARD_PAD()
+#else
+#define HAZARD_PAD() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+#endif
 #define HD 64
 #define NT_MAX 13            // 13 * 16 = 208 >= 197 tokens
 #define ROWS_PAD 224         // 14 * 16: k-steps pair two 16-row tiles
@@ -422,10 +429,12 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
         // conditional block of the step -- comes BEFORE the MFMAs.
         BSTAMP(4);
         bool k4[2][4] = {{true, true, true, true}, {true, true, true, true}};
+#ifndef ATTN_HAZARD_DEMO
         if (drop_thr) {
             keep4(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4[0]);
             keep4(drop_key, rowpair, t0 * 16 + 16 + 4 * g, drop_thr, k4[1]);
         }
+#endif
         BSTAMP(5);
         // Staged so that at most 16 operand registers are live: K rows -> S^T, V rows -> dP^T, softmax backward, K^T columns -> dQ^T.
         // (With every read of the step hoisted to the top the kernel spills ~55 registers at the 128-VGPR budget of 13 waves.)
@@ -454,6 +463,12 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
             dp[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v11, do1, dp[1], 0, 0, 0);
         }
         BSTAMP(7);
+#ifdef ATTN_HAZARD_DEMO      // the round-3 bug, kept as the build-time guard's test case (tools/check_mfma_hazard.py): a skipped `if` right after the MFMAs
+        if (drop_thr) {
+            keep4(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4[0]);
+            keep4(drop_key, rowpair, t0 * 16 + 16 + 4 * g, drop_thr, k4[1]);
+        }
+#endif
         float pdv[2][4], dsv[2][4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -511,7 +526,7 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
         } else {
             for (int ks = 0; ks < nsteps; ++ks) kstep(ks);
         }
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // the loop exit is a branch: pad the MFMA -> VALU wait states by hand
+        HAZARD_PAD();     // the loop exit is a branch: pad the MFMA -> VALU wait states by hand
         // acc[tt][r] = d{V,K}[key 32 i + 16 tt + li][d = 16 dtj + 4 g + r]  ->  the dead rows of the V / K image
         char* dst = pj ? kimg : vimg;
         const float sc = pj ? scale : 1.0f;

@@ -20,6 +20,13 @@
 #include "common.h"
 #include "uvit_internal.h"
 
+// hand-placed MFMA -> VALU wait states where a branch follows an MFMA chain (tools/check_mfma_hazard.py is the build-time guard;
+// -DATTN_NO_HAZARD_PAD builds the deliberately broken variant the guard must flag)
+#ifdef ATTN_NO_HAZARD_PAD
+#define HAZARD_PAD()
+#else
+#define HAZARD_PAD() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+#endif
 #define HD 64
 #define NT_MAX 13
 #define ROWS_PAD 224
@@ -288,6 +295,21 @@ __device__ __forceinline__ float back_cov(float dA, float dside, float y) {   //
 #define F2_SB (F2_ROWS * 32)                  // 6,656 B
 #define F2_LDS (4 * F2_IMG + 2 * F2_SLOT + 6 * F2_SB + 2 * 16 * 4)      // 162,944 B
 #define F2_BWAVES 8
+// Diagnostic build only (-DATTN2_STAMP, tools/stamp_attn2.py): s_memtime stamps of waves 0, 4 and 8 of every workgroup; never in libuvit.so
+#ifdef ATTN2_STAMP
+#define F2S_WG 2048
+__device__ unsigned long long g_attn2_stamps[F2S_WG * 3 * 32];
+#define F2_WSLOT (wave == 0 ? 0 : wave == 4 ? 1 : wave == 8 ? 2 : -1)
+#define F2STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        if ((threadIdx.x & 63) == 0 && F2_WSLOT >= 0 && blockIdx.x < F2S_WG) g_attn2_stamps[(blockIdx.x * 3 + F2_WSLOT) * 32 + (k)] = t_; } while (0)
+#define F2SUB(k) do { if (i == 6) F2STAMP(k); } while (0)
+extern "C" int uvit_debug_attn2_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn2_stamps), sizeof(g_attn2_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define F2STAMP(k)
+#define F2SUB(k)
+#endif
 #ifndef F2_UNROLL
 #define F2_UNROLL 7
 #endif
@@ -356,6 +378,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
     const bf16* dcbase = d_c + (size_t)b * N * C + h * HD;
     const bool active = NT_C ? true : wave < nt;
     const int q = wave * 16 + li, qr = q < N ? q : N - 1;
+    F2STAMP(0);
 
     // ---- dM, dC images by LDS-DMA (row blocks of 8; blocks beyond the last tile are never read)
     for (int p = wave; p < 2 * (F2_ROWS / 8); p += F2_WAVES) {
@@ -448,8 +471,11 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
         }
     };
     bias_fetch(0, lane);
+    F2STAMP(1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    F2STAMP(2);
     __syncthreads();
+    F2STAMP(3);
 
     f32x4 dam[4], dac[4];
 #pragma unroll
@@ -470,6 +496,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
         bool k4[4] = {true, true, true, true};
         if (drop_thr) keep4b(drop_key, ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1), i * 16 + 4 * g, drop_thr, k4);
         const float4 cv4 = *(const float4*)(cjr + (i & 1) * 16 + 4 * g);
+        F2SUB(24);
         f32x4 sacc, pm, pc;
         {
             const bf16x8 k0 = rowf(bm, li, g), k1 = rowf(bm, li, 4 + g);
@@ -485,6 +512,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, a1, sacc, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        F2SUB(25);
         {
             const bf16x8 v0 = rowf(vimg, li, g), v1 = rowf(vimg, li, 4 + g);
             const bf16x8 d0 = rowf(dmimg, q, g), d1 = rowf(dmimg, q, 4 + g);
@@ -499,6 +527,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, d0, z, 0, 0, 0);
             pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, d1, pc, 0, 0, 0);
         }
+        F2SUB(26);
         const float bb[4] = {bcur.x, bcur.y, bcur.z, bcur.w};
         const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
         float pdv[4], p2v[4], gwv[4], dsv[4];
@@ -526,11 +555,13 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
         }
         const s16x4 gwf = __builtin_bit_cast(s16x4, gw);
         __builtin_amdgcn_sched_barrier(0);
+        F2SUB(27);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             dam[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(col_frag16(bm, dt * 16, lane), gwf, dam[dt], 0, 0, 0);
             dac[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(col_frag16(bc, dt * 16, lane), gwf, dac[dt], 0, 0, 0);
         }
+        F2SUB(28);
     };
 
     // ================= B_i (waves 0..7): key-side gradients of the step's 16 keys, contracted over every query
@@ -575,7 +606,8 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             const int nk = (nt + 1) >> 1;
             for (int ks = 0; ks < nk; ++ks) kstep(ks);
         }
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");     // loop exit / role branches: pad the MFMA -> VALU wait states by hand
+        HAZARD_PAD();     // loop exit / role branches: pad the MFMA -> VALU wait states by hand
+        if (i == 5) F2STAMP(22);
         // acc*[r] = gradient [key li][feature 16 dtj + 4 g + r]
         if (key < N) {
             bf16* om = dqkv_m + ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
@@ -607,9 +639,11 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
     for (int i = 0; i <= nt; ++i) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        F2SUB(21);
         if (wave < F2_BWAVES) {
             if (i > 0) B_step(i - 1, ln);
             __builtin_amdgcn_sched_barrier(0);
+            F2SUB(23);
             if (i < nt && active) A_step(i, ln);
         } else {
             if (lw < 4) {
@@ -619,11 +653,15 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
                 v_dma(i + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            F2SUB(23);
             if (i < nt && active) A_step(i, ln);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        F2SUB(29);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        F2SUB(30);
+        F2STAMP(4 + (i < 14 ? i : 14));
     }
     if (active) {
         dside = gsum4(dside);                                  // d r_i = sum_j dL/dW_ij
@@ -646,6 +684,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             }
         }
     }
+    F2STAMP(19);
 }
 
 // Bias gradient from the dS tiles the fused kernel streamed out: slab[h][key][q] += sum_b dS_b[h][q][key].
@@ -747,3 +786,12 @@ int uvit_attn2_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int acc
     hipLaunchKernelGGL(attn2_dbias_reduce_kernel, dim3(H * nt * nq4, DBR2_PARTS), dim3(256), 0, s, (const uint2*)ds_ws, dbias_slab, B, H, N, NP);
     return uvit_check_launch();
 }
+
+#ifdef ATTN2_STAMP
+extern "C" int uvit_debug_attn2_bwd(const void* qkv_m, const void* qkv_c, const void* o_m, const void* o_c, const void* d_m, const void* d_c,
+                                    const float* biasP, const float* lse, float* delta, void* dqkv_m, void* dqkv_c, void* ds_ws, int B, int H,
+                                    int N, float p_drop, void* stream) {
+    return uvit_attn2_bwd_launch(qkv_m, qkv_c, o_m, o_c, d_m, d_c, biasP, lse, delta, dqkv_m, dqkv_c, ds_ws, ds_ws != nullptr, B, H, N, 208,
+                                 0.125f, p_drop, 1u, 0u, (hipStream_t)stream);
+}
+#endif

@@ -15,6 +15,11 @@ for f in gemm attention attention2 norm elementwise optim engine; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
+# Build-time guard (round 4): no taken branch between an MFMA and the first read of its result without the wait states the MFMA
+# needs -- hipcc pads the fall-through path only (tools/check_mfma_hazard.py; tools/micro/mfma_branch_hazard.hip is the flagged case).
+if [ -z "$UVIT_SKIP_HAZARD_CHECK" ]; then
+  python3 ../../tools/check_mfma_hazard.py --compile gemm.hip attention.hip attention2.hip $UVIT_EXTRA_FLAGS || { echo "MFMA hazard check FAILED"; exit 1; }
+fi
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" obj/*.o
 echo "$HASH" > "$OUT.hash"
 echo "built $OUT"

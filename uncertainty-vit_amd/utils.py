@@ -244,6 +244,30 @@ class ModelEmaV2(torch.nn.Module):
         self._update(model, update_fn=lambda e, m: m)
 
 
+def broadcast_model_state(model, model_ema=None, optimizer=None, src=0):
+    """What DDP's constructor does at `run_cyclical.py:516` (broadcast of rank 0's parameters and buffers), for the flat arenas:
+    one `dist.broadcast` of the parameter arena, one of the EMA teacher's, one each of the optimizer's moment arenas (a resumed
+    run).  Called after the checkpoint load, so that every rank starts from rank 0's state whatever the init or resume path did.
+    No-op without an initialised process group or with one rank.  Returns the number of broadcasts issued."""
+    if not is_dist_avail_and_initialized() or get_world_size() < 2:
+        return 0
+    n = 0
+    arenas = [getattr(model, "_arena", None)]
+    if model_ema is not None:
+        arenas.append(getattr(model_ema.module, "_arena", None))
+    if optimizer is not None:
+        arenas += [getattr(optimizer, "exp_avg", None), getattr(optimizer, "exp_avg_sq", None)]
+    with torch.no_grad():
+        for a in arenas:
+            if a is not None:
+                dist.broadcast(a, src=src)
+                n += 1
+    for m in (model, model_ema.module if model_ema is not None else None):
+        if m is not None and hasattr(m, "mark_weights_changed"):
+            m.mark_weights_changed()          # the bf16 shadows are rebuilt from the arena before the next step
+    return n
+
+
 def get_state_dict(model, unwrap_fn=None):
     return (model.module if hasattr(model, "module") and not isinstance(model, ModelEmaV2) else model).state_dict()
 
