@@ -1,7 +1,7 @@
 """Diagnostic: time line of the fused two-stream attention backward from in-kernel s_memtime stamps (segment shares, not run time).
 
 Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DUVIT_SRC_HASH='"dbg"' -DATTN2_STAMP \
-            -shared uncertainty-vit_amd/csrc/attention2.hip uncertainty-vit_amd/csrc/elementwise.hip -o uncertainty-vit_amd/libattn2_stamp.so
+            -shared uncertainty-vit_amd/csrc/attention2.hip uncertainty-vit_amd/csrc/optim.hip -o uncertainty-vit_amd/libattn2_stamp.so
 Run on the GPU box:  python tools/stamp_attn2.py [p_drop] [with_dbias]"""
 import ctypes as C
 import os

@@ -17,6 +17,7 @@
 //   bwd q   : + dMean, dCov rows in registers -> dq, dcov_q, rel-pos-bias gradient slabs, delta
 //   bwd kv  : images Am, Ac (queries), dMean, dCov; the wave's keys in registers -> dk, dcov_k, dv, dcov_v
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 #include "uvit_internal.h"
 
@@ -294,7 +295,6 @@ __device__ __forceinline__ float back_cov(float dA, float dside, float y) {   //
 #define F2_SLOT (4 * 16 * 128)                // 8,192 B: Bm, Bc, V, CV rows of one 16-key step
 #define F2_SB (F2_ROWS * 32)                  // 6,656 B
 #define F2_LDS (4 * F2_IMG + 2 * F2_SLOT + 6 * F2_SB + 2 * 16 * 4)      // 162,944 B
-#define F2_BWAVES 8
 // Diagnostic build only (-DATTN2_STAMP, tools/stamp_attn2.py): s_memtime stamps of waves 0, 4 and 8 of every workgroup; never in libuvit.so
 #ifdef ATTN2_STAMP
 #define F2S_WG 2048
@@ -380,57 +380,70 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
     const int q = wave * 16 + li, qr = q < N ? q : N - 1;
     F2STAMP(0);
 
-    // ---- dM, dC images by LDS-DMA (row blocks of 8; blocks beyond the last tile are never read)
-    for (int p = wave; p < 2 * (F2_ROWS / 8); p += F2_WAVES) {
-        const int img = p & 1, rb = p >> 1;
-        if (rb * 8 >= nt * 16) continue;
-        dma_rows8_2(img ? dcimg : dmimg, rb, img ? dcbase : dmbase, (size_t)C, 0, N, lane);
-    }
-    // ---- key ring loaders (waves 8..11): lane -> (tensor, row, chunk) of a step's 16 rows of k / cov_k
-    const int lw = wave - F2_BWAVES;                                   // 0..3 loaders of Bm / Bc, 4: the V / CV DMA
-    const int l_t = lane >> 5, l_row = 4 * (lw & 3) + ((lane >> 3) & 3), l_ch = lane & 7;
-    bf16x8 kraw = {};
-    auto k_fetch = [&](int step) {                                     // raw 16 B of key row 16 step + l_row
+    // ---- key ring: a step's 16 rows of k, cov_k are 256 chunk tasks (tensor, row, 16-B chunk), one per lane of waves 0..3 (the role with the shortest B chain): fetched
+    //      at the start of the iteration before, transformed (sigmoid / sqrt sigmoid, column term c_j on the way) and written at its
+    //      end; the step's v, cov_v rows arrive by LDS-DMA (wave 12: 4 pieces of 8 rows)
+    auto k_fetch = [&](int step, int lane) -> bf16x8 {
+        const int l_t = lane >> 5, l_row = 4 * (wave & 3) + ((lane >> 3) & 3), l_ch = lane & 7;
         const int key = step * 16 + l_row;
         const int kr = key < N ? key : N - 1;
-        kraw = *(const bf16x8*)((l_t ? base_c : base_m) + C + (size_t)kr * ld + l_ch * 8);
+        return *(const bf16x8*)((l_t ? base_c : base_m) + C + (size_t)kr * ld + l_ch * 8);
     };
-    auto k_write = [&](int step) {                                     // transform -> ring slot, column term c_j
+    auto k_write = [&](int step, const bf16x8 kraw, int lane) {
+        const int l_t = lane >> 5, l_row = 4 * (wave & 3) + ((lane >> 3) & 3), l_ch = lane & 7;
         char* slot = ring + (step & 1) * F2_SLOT;
         const int key = step * 16 + l_row;
         float part;
         bf16x8 o = l_t ? tr_chunk<TR_SQRT_SIG>(kraw, 1.0f, part) : tr_chunk<TR_SIG>(kraw, 1.0f, part);
         if (key >= N) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(0.f);
         }
         *(bf16x8*)(slot + l_t * 2048 + img_off2(l_row, l_ch)) = o;
-        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+        // sum over the row's 8 chunk lanes by DPP row shifts (lane 8 k of a row ends with lanes 8 k .. 8 k + 7), then the other tensor
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x101, 0xf, 0xf, true));   // row_shl:1
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x102, 0xf, 0xf, true));   // row_shl:2
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x104, 0xf, 0xf, true));   // row_shl:4
         part += __shfl_xor(part, 32, 64);
         if ((lane & 39) == 0) cjr[(step & 1) * 16 + l_row] = part;
     };
-    auto v_dma = [&](int step) {                                       // V, CV rows of the step: 4 pieces of 8 rows
+    auto v_dma = [&](int step, int lane) {
         char* slot = ring + (step & 1) * F2_SLOT;
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc)
             dma_rows8_2(slot + 4096 + (pc >> 1) * 2048, pc & 1, ((pc >> 1) ? base_c : base_m) + 2 * C, ld, step * 16, N, lane);
     };
-    if (lw >= 0 && lw < 4) { k_fetch(0); }
-    if (lw == 4) v_dma(0);
 
-    // ---- this wave's queries: A_m, A_c rows through the transform into the images (rows >= N zero), row term r_i,
-    //      delta = dM.mean + 2 dC.cov, LSE
+    // ---- preamble: every global request first (dM, dC images by LDS-DMA; this wave's raw q / cov_q rows, its dM / dC / mean / cov
+    //      rows for delta; wave 12: step 0 of the key ring), then the transforms
+    for (int p = wave; p < 2 * (F2_ROWS / 8); p += F2_WAVES) {
+        const int img = p & 1, rb = p >> 1;
+        if (rb * 8 >= nt * 16) continue;
+        dma_rows8_2(img ? dcimg : dmimg, rb, img ? dcbase : dmbase, (size_t)C, 0, N, lane);
+    }
     float ri = 0.f, dl = 0.f, lse_q = 1e30f;        // padded query lanes: p = exp2(.. - 1e30) = 0
+    bf16x8 kraw0 = {};
+    if (wave < 4) kraw0 = k_fetch(0, lane);
+    if (wave == 12) v_dma(0, lane);
     if (active) {
+        bf16x8 vm[2], vc[2], dmf[2], dcf[2], omf[2], ocf[2];
+        const size_t orow = ((size_t)b * N + qr) * C + h * HD;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int row = wave * 16 + 8 * k + (lane >> 3);
+            const int rr = row < N ? row : N - 1;
+            vm[k] = *(const bf16x8*)(base_m + (size_t)rr * ld + (lane & 7) * 8);
+            vc[k] = *(const bf16x8*)(base_c + (size_t)rr * ld + (lane & 7) * 8);
+            dmf[k] = *(const bf16x8*)(d_m + orow + k * 32 + g * 8); dcf[k] = *(const bf16x8*)(d_c + orow + k * 32 + g * 8);
+            omf[k] = *(const bf16x8*)(o_m + orow + k * 32 + g * 8); ocf[k] = *(const bf16x8*)(o_c + orow + k * 32 + g * 8);
+        }
+        if (q < N) lse_q = lse[(size_t)bh * N + q];
         float side[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int row = wave * 16 + 8 * k + (lane >> 3), ch = lane & 7;
-            const int rr = row < N ? row : N - 1;
-            const bf16x8 vm = *(const bf16x8*)(base_m + (size_t)rr * ld + ch * 8);
-            const bf16x8 vc = *(const bf16x8*)(base_c + (size_t)rr * ld + ch * 8);
             float pm_, pc_;
-            bf16x8 om_ = tr_chunk<TR_SIG>(vm, scale, pm_), oc_ = tr_chunk<TR_SQRT_SIG>(vc, 1.0f, pc_);
+            bf16x8 om_ = tr_chunk<TR_SIG>(vm[k], scale, pm_), oc_ = tr_chunk<TR_SQRT_SIG>(vc[k], 1.0f, pc_);
             if (row >= N) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { om_[j] = f2bf(0.f); oc_[j] = f2bf(0.f); }
@@ -439,26 +452,19 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             *(bf16x8*)(qc + img_off2(row, ch)) = oc_;
             float s_ = pm_ + pc_;
             s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64);
-            side[k] = s_;                                              // row 8 k + (lane >> 3)
+            side[k] = s_;                                              // row term of row 8 k + (lane >> 3)
         }
         // lane (g, li) wants the row term of query li: rows 0..7 sit in side[0] of lanes 8 r, rows 8..15 in side[1]
         const float s0 = __shfl(side[0], (li & 7) * 8, 64), s1 = __shfl(side[1], (li & 7) * 8, 64);
         ri = li < 8 ? s0 : s1;
-        const size_t orow = ((size_t)b * N + qr) * C + h * HD;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8 dmf = *(const bf16x8*)(d_m + orow + kk * 32 + g * 8), dcf = *(const bf16x8*)(d_c + orow + kk * 32 + g * 8);
-            const bf16x8 omf = *(const bf16x8*)(o_m + orow + kk * 32 + g * 8), ocf = *(const bf16x8*)(o_c + orow + kk * 32 + g * 8);
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f(dmf[j]) * bf2f(omf[j]) + 2.0f * bf2f(dcf[j]) * bf2f(ocf[j]);
-        }
-        dl = gsum4(dl);
-        if (q < N) {
-            lse_q = lse[(size_t)bh * N + q];
-            if (g == 0) delta[(size_t)bh * N + q] = dl;
-        }
+            for (int j = 0; j < 8; ++j) dl += bf2f(dmf[kk][j]) * bf2f(omf[kk][j]) + 2.0f * bf2f(dcf[kk][j]) * bf2f(ocf[kk][j]);
+        dl = gsum4(dl);                                               // delta_i = dM.mean + 2 dC.cov
+        if (q < N && g == 0) delta[(size_t)bh * N + q] = dl;
     }
-    if (lw >= 0 && lw < 4) { k_write(0); if (1 < nt) k_fetch(1); }
+    if (wave < 4) k_write(0, kraw0, lane);
     float4 bnext;
     auto bias_fetch = [&](int t, int lane) {
         const int g = lane >> 4, q = wave * 16 + (lane & 15);
@@ -483,7 +489,7 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
     float dside = 0.f;
 
     // ================= A_i: this wave's 16 queries against the step's key tile
-    auto A_step = [&](int i, int lane) {
+    auto A_step = [&](int i, int lane) __attribute__((always_inline)) {
         // per-lane offsets are re-derived from an opaque copy of the lane id every step: hoisted out of the loop they cost ~20 VGPRs
         const int g = lane >> 4, li = lane & 15, q = wave * 16 + li;
         const char* slot = ring + (i & 1) * F2_SLOT;
@@ -564,39 +570,40 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
         F2SUB(28);
     };
 
-    // ================= B_i (waves 0..7): key-side gradients of the step's 16 keys, contracted over every query
-    const int role = wave >> 2, dtj = wave & 3;      // role 0: dB_m, dB_c, column sum of gW;  role 1: dV, dCV
-    auto B_step = [&](int i, int lane) {
+    // ================= B_i (waves 0..11): key-side gradients of the step's 16 keys, contracted over every query.
+    // role 0 (waves 0..3): dB_m tile + the column sum of gW;  role 1 (waves 4..7): dB_c tile + the same column sum;
+    // role 2 (waves 8..11): dV and dCV tiles.  (The column sum d c_j = sum_i gW_ij is an all-ones A operand against the gW
+    // fragments the wave reads anyway: cheaper than handing it from one wave to another.)
+    const int dtj = wave & 3;
+    bf16x4 xnext = {};                    // the raw input B_i's chain rule needs, requested a whole iteration ahead
+    auto x_fetch = [&](int i, int lane) {
+        const int g = lane >> 4, key = i * 16 + (lane & 15);
+        const int kr = key < N ? key : N - 1;
+        const int role = wave >> 2;
+        xnext = *(const bf16x4*)((role == 0 ? base_m + C : role == 1 ? base_c + C : base_c + 2 * C) + (size_t)kr * ld + dtj * 16 + 4 * g);
+    };
+    auto B_step = [&](auto role_c, int i, int lane, const bf16x4 x0) __attribute__((always_inline)) {
+        constexpr int role = decltype(role_c)::value;
         const int g = lane >> 4, li = lane & 15;
         const char* pbuf = sbuf + (i & 1) * 3 * F2_SB;
         const int key = i * 16 + li;
-        const int kr = key < N ? key : N - 1;
-        // the raw inputs the chain rule needs, requested in front of the MFMA chain
-        const bf16* rm = base_m + (size_t)kr * ld + dtj * 16 + 4 * g;
-        const bf16* rc = base_c + (size_t)kr * ld + dtj * 16 + 4 * g;
-        bf16x4 x0, x1;
-        if (role == 0) { x0 = *(const bf16x4*)(rm + C); x1 = *(const bf16x4*)(rc + C); }
-        else { x0 = *(const bf16x4*)(rc + 2 * C); x1 = x0; }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-        const char* img0 = role == 0 ? qa : dmimg;
-        const char* img1 = role == 0 ? qc : dcimg;
-        const char* sb0 = role == 0 ? pbuf + 2 * F2_SB : pbuf;
-        const char* sb1 = role == 0 ? pbuf + 2 * F2_SB : pbuf + F2_SB;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const char* img0 = role == 0 ? qa : role == 1 ? qc : dmimg;
+        const char* sb0 = role == 2 ? pbuf : pbuf + 2 * F2_SB;
         const bf16 one = f2bf(1.0f);
         const bf16x8 ones = {one, one, one, one, one, one, one, one};
-        auto kstep = [&](int ks) {
+        auto kstep = [&](int ks) __attribute__((always_inline)) {
             const bool hk = 2 * ks + 1 < nt;
             const int r_lo = 32 * ks, r_hi = hk ? r_lo + 16 : r_lo;
             const bf16x8 a0 = colf(img0, r_lo, r_hi, dtj * 16, lane);
-            const bf16x8 a1 = colf(img1, r_lo, r_hi, dtj * 16, lane);
             const bf16x8 b0 = sb16_col_frag(sb0, r_lo, r_hi, hk, lane);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc0, 0, 0, 0);
-            if (role == 0) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0, acc2, 0, 0, 0);
-            } else {
-                const bf16x8 b1 = sb16_col_frag(sb1, r_lo, r_hi, hk, lane);
+            if constexpr (role == 2) {
+                const bf16x8 a1 = colf(dcimg, r_lo, r_hi, dtj * 16, lane);
+                const bf16x8 b1 = sb16_col_frag(pbuf + F2_SB, r_lo, r_hi, hk, lane);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc1, 0, 0, 0);
+            } else {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b0, acc1, 0, 0, 0);
             }
         };
         if constexpr (NT_C != 0) {
@@ -606,78 +613,96 @@ void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restri
             const int nk = (nt + 1) >> 1;
             for (int ks = 0; ks < nk; ++ks) kstep(ks);
         }
-        HAZARD_PAD();     // loop exit / role branches: pad the MFMA -> VALU wait states by hand
+        HAZARD_PAD();     // loop exit / exec-mask branch: pad the MFMA -> VALU wait states by hand
         if (i == 5) F2STAMP(22);
-        // acc*[r] = gradient [key li][feature 16 dtj + 4 g + r]
+        // acc*[r] = gradient [key li][feature 16 dtj + 4 g + r];  roles 0, 1: acc1[.] = d c_j = sum_i dL/dW_ij
         if (key < N) {
-            bf16* om = dqkv_m + ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
-            bf16* oc = dqkv_c + ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
+            const size_t o = ((size_t)b * N + key) * ld + h * HD + dtj * 16 + 4 * g;
             bf16x4 r0, r1;
-            if (role == 0) {
-                const float dsj = acc2[0];                    // d c_j = sum_i dL/dW_ij (every row of the all-ones product)
+            if constexpr (role == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    r0[r] = f2bf(back_mean(-2.0f * acc0[r], dsj, bf2f(x0[r]), 1.0f));
-                    r1[r] = f2bf(back_cov(-2.0f * acc1[r], dsj, bf2f(x1[r])));
-                }
-                *(bf16x4*)(om + C) = r0;
-                *(bf16x4*)(oc + C) = r1;
+                for (int r = 0; r < 4; ++r) r0[r] = f2bf(back_mean(-2.0f * acc0[r], acc1[0], bf2f(x0[r]), 1.0f));
+                *(bf16x4*)(dqkv_m + o + C) = r0;
+            } else if constexpr (role == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) r0[r] = f2bf(back_cov(-2.0f * acc0[r], acc1[0], bf2f(x0[r])));
+                *(bf16x4*)(dqkv_c + o + C) = r0;
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     r0[r] = f2bf(acc0[r]);
                     r1[r] = f2bf(acc1[r] * fminf(bf2f(x0[r]), 1.0f));                // ELU' of the cov_v pre-activation
                 }
-                *(bf16x4*)(om + 2 * C) = r0;
-                *(bf16x4*)(oc + 2 * C) = r1;
+                *(bf16x4*)(dqkv_m + o + 2 * C) = r0;
+                *(bf16x4*)(dqkv_c + o + 2 * C) = r1;
             }
         }
     };
+    // the role is wave-uniform but a run-time value: three instantiations, chosen in front of the chain (a branch BETWEEN the MFMAs of
+    // one chain is what tools/check_mfma_hazard.py flagged in the single-instantiation form)
+    auto B_any = [&](int i, int lane, const bf16x4 x0) __attribute__((always_inline)) {
+        if (wave < 4) B_step(std::integral_constant<int, 0>{}, i, lane, x0);
+        else if (wave < 8) B_step(std::integral_constant<int, 1>{}, i, lane, x0);
+        else B_step(std::integral_constant<int, 2>{}, i, lane, x0);
+    };
+    if (wave < F2_WAVES - 1) x_fetch(0, lane);
 
-    // iteration i: B_{i-1} / the ring fill for step i + 1, then A_i, then the step's barrier
+    // iteration i: B_{i-1} (waves 0..11), then A_i, then (waves 0..3) the transformed key rows of step i + 1, then the step's barrier.
+    // Only the LDS traffic is waited for at the barrier (plus wave 12's DMA): the dS and gradient stores drain behind the next steps.
 #pragma unroll 1
-    for (int i = 0; i <= nt; ++i) {
+    for (int i = 0; i < nt; ++i) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         F2SUB(21);
-        if (wave < F2_BWAVES) {
-            if (i > 0) B_step(i - 1, ln);
+        const bool more = i + 1 < nt;
+        if (wave < F2_WAVES - 1) {
+            const bf16x4 xcur = xnext;
+            x_fetch(i, ln);                                   // for B_i, one iteration from now
+            bf16x8 kraw = {};
+            if (wave < 4 && more) kraw = k_fetch(i + 1, ln);
+            if (i > 0) B_any(i - 1, ln, xcur);
             __builtin_amdgcn_sched_barrier(0);
             F2SUB(23);
-            if (i < nt && active) A_step(i, ln);
+            if (active) A_step(i, ln);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave < 4 && more) k_write(i + 1, kraw, ln);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
-            if (lw < 4) {
-                if (i + 1 < nt) k_write(i + 1);
-                if (i + 2 < nt) k_fetch(i + 2);
-            } else if (i + 1 < nt) {
-                v_dma(i + 1);
-            }
+            if (more) v_dma(i + 1, ln);
             __builtin_amdgcn_sched_barrier(0);
             F2SUB(23);
-            if (i < nt && active) A_step(i, ln);
+            if (active) A_step(i, ln);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         F2SUB(29);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         F2SUB(30);
         F2STAMP(4 + (i < 14 ? i : 14));
     }
+    // ---- tail: the raw q / cov_q values the query-side chain rule needs are requested in front of the last B step
+    bf16x4 xq[4], xcq[4];
+    if (active && q < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            xq[dt] = *(const bf16x4*)(base_m + (size_t)q * ld + dt * 16 + 4 * g);
+            xcq[dt] = *(const bf16x4*)(base_c + (size_t)q * ld + dt * 16 + 4 * g);
+        }
+    }
+    if (wave < F2_WAVES - 1) B_any(nt - 1, lane, xnext);
+    F2STAMP(18);
     if (active) {
         dside = gsum4(dside);                                  // d r_i = sum_j dL/dW_ij
         if (q < N) {
-            const bf16* xm = base_m + (size_t)q * ld + 4 * g;
-            const bf16* xc = base_c + (size_t)q * ld + 4 * g;
             bf16* om = dqkv_m + ((size_t)b * N + q) * ld + h * HD + 4 * g;
             bf16* oc = dqkv_c + ((size_t)b * N + q) * ld + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x4 vm = *(const bf16x4*)(xm + dt * 16), vc = *(const bf16x4*)(xc + dt * 16);
                 bf16x4 rm, rc;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {       // dA = -2 sum_j gW B_j
-                    rm[r] = f2bf(back_mean(-2.0f * dam[dt][r], dside, bf2f(vm[r]), scale));
-                    rc[r] = f2bf(back_cov(-2.0f * dac[dt][r], dside, bf2f(vc[r])));
+                    rm[r] = f2bf(back_mean(-2.0f * dam[dt][r], dside, bf2f(xq[dt][r]), scale));
+                    rc[r] = f2bf(back_cov(-2.0f * dac[dt][r], dside, bf2f(xcq[dt][r])));
                 }
                 *(bf16x4*)(om + dt * 16) = rm;
                 *(bf16x4*)(oc + dt * 16) = rc;
