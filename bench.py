@@ -11,8 +11,9 @@ torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 A "step" is one full iteration of engine_for_cyclical.train_one_epoch on one synthetic batch that
 is already resident in HBM: teacher forward -> targets -> student forward (attn-drop 0.05,
 drop-path 0.25) -> SmoothL1 -> backward -> [gradient all-reduce] -> clip + AdamW -> EMA.
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM
-gemm_nt256_kernel, timed on its fc1 bias+GELU launches with HIP events on the launch stream);
+Rank 0 prints ONE JSON line.  `roofline` is for the largest kernel by time (the bf16 MFMA GEMM
+gemm_nt256_kernel in its residual-epilogue instantiation: attention proj + MLP fc2; the fc1 launches ride along per
+instantiation), timed with HIP events on the launch stream;
 `cpu_baseline` times the oracle (the CPU restatement, kind "port") on the host cores.
 """
 import argparse
@@ -32,26 +33,60 @@ GFLOP_PER_IMAGE = 140.698        # student fwd + bwd + tea
 GFLOP_BY_MODEL = {"beit_base_patch16_224": 140.698, "dist_beit_base_patch16_224": 281.396,
                   "beit_large_patch16_224": 492.876, "dist_beit_large_patch16_224": 985.752}
 PEAK_BF16 = 2.5e15               # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# fc1 GEMM (M=25216, N=3072, K=768): algorithmic HBM bytes per launch = A + W read, h + gelu(h) written (bf16)
-ALGO_BYTES = 2 * (25216 * 768 + 3072 * 768 + 2 * 25216 * 3072)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3_pmc_hbm.txt")      # written by tools/pmc_run.sh (two separate --pmc passes)
+PEAK_HBM = 8.0e12                # B/s (MI355X_MICROARCH.md)
+# committed rocprofv3 summaries of THIS round that the live numbers must agree with (tools/pmc_run.sh, tools/prof_step.sh)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round4_pmc_hbm.txt")
+KERNEL_STATS = os.path.join(ROOT, "profiles", "round4_step_kernel_stats_singlestream.txt")
+# the four bracketed forward Linears of a block (uvit_engine_profile_read_kind): kind id, kernel instantiation, PMC tag
+PROF_KINDS = {"fc1_teacher": (0, "gemm_nt256_kernel<EPI_GELU, MT 4, persistent> (fc1, bias + GELU)", "gemm_nt256_kernel<2, 4", None),
+              "fc1_student": (1, "gemm_nt256_kernel<EPI_GELU_DG, MT 4, persistent> (fc1, bias + GELU, also stores GELU')", "gemm_nt256_kernel<8, 4", None),
+              "proj": (2, "gemm_nt256_kernel<EPI_RESID, MT 5> (attention proj: bias, LayerScale, DropPath, fp32 residual)", "gemm_nt256_kernel<3, 5", "[proj]"),
+              "fc2": (3, "gemm_nt256_kernel<EPI_RESID, MT 5> (MLP fc2: bias, LayerScale, DropPath, fp32 residual)", "gemm_nt256_kernel<3, 5", "[fc2]")}
 
 
-def pmc_traffic_bytes(path=PMC_SUMMARY):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary: mean over its two instantiations (teacher
-    launch: GELU; student launch: GELU + GELU') of 2 x FETCH_SIZE + WRITE_SIZE, counters in KiB (FETCH_SIZE reads half the bytes of a wide
-    coalesced stream on gfx950: MI355X_MICROARCH.md, HBM).  None when the summary is not there."""
+def pmc_traffic(path=PMC_SUMMARY):
+    """HBM-side bytes per launch of each bracketed Linear from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE
+    passes; counters in KiB; FETCH_SIZE reads half the bytes of a wide coalesced stream on gfx950 and is doubled: MI355X_MICROARCH.md,
+    HBM).  -> {name: {"fetch": B, "write": B, "dram_read": B or None}}; empty when the summary is not there."""
+    out = {}
     try:
-        vals = {}
+        lines = open(path).read().splitlines()
+    except OSError:
+        return out
+    for name, (_, _, tag, sub) in PROF_KINDS.items():
+        d = {}
+        for line in lines:
+            if tag not in line or "mean" not in line or (sub and sub not in line) or (not sub and "[" in line.split("mean")[0].split(tag)[1]):
+                continue
+            try:
+                val = float(line.split("mean")[1].split(",")[0])
+            except (ValueError, IndexError):
+                continue
+            head = line.split(":")[0].strip().lower()
+            if head.startswith("fetch"):
+                d["fetch"] = int(2 * val * 1024)
+            elif head.startswith("write"):
+                d["write"] = int(val * 1024)
+            elif "rdreq_dram" in head:
+                d["dram_read"] = int(val * 64)          # 64-B requests that reached HBM itself (not served by the Infinity Cache)
+        if "fetch" in d and "write" in d:
+            out[name] = d
+    return out
+
+
+def rocprof_avg_us(path=KERNEL_STATS):
+    """avg us per launch by kernel-name prefix from the committed single-stream kernel-stats summary (tools/prof_summary.py)."""
+    out = {}
+    try:
         for line in open(path):
-            for tag in ("gemm_nt256_kernel<2, 4", "gemm_nt256_kernel<8, 4"):
-                if tag in line and "mean" in line:
-                    kind = "fetch" if line.startswith("fetch") else "write"
-                    vals[(tag, kind)] = float(line.split("mean")[1].split(",")[0])
-        per = [2 * vals[(t, "fetch")] + vals[(t, "write")] for t in ("gemm_nt256_kernel<2, 4", "gemm_nt256_kernel<8, 4")]
-        return int(sum(per) / len(per) * 1024)
-    except (OSError, KeyError, ValueError, IndexError):
-        return None
+            parts = line.split()
+            if len(parts) >= 5 and not line.startswith("#") and parts[-1].replace(".", "", 1).isdigit():
+                out[line[:72].strip()] = float(parts[-2])
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 # the reference's OWN engine_for_cyclical.train_one_epoch timed in the build container (tools/time_reference.py; the
 # reference cannot travel to the GPU box): bs=4, 8 threads, 3 timed steps -- quoted beside the port's figure
 REFERENCE_ENGINE_BUILD_CONTAINER = {"img_per_s": 2.292, "s_per_step": 1.745, "threads": 8, "batch": 4, "timed_steps": 3,
@@ -278,21 +313,40 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
-    tot, n, fl = C.c_double(), C.c_int(), C.c_double()
-    check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
-    in_ms, in_n, flops = tot.value / max(n.value, 1), n.value, fl.value
-    alone_ms = None
+    def read_kinds():
+        """{name: (avg ms per launch, launches, flops per launch, algorithmic bytes per launch)} of the bracketed Linears"""
+        res = {}
+        for name, (kind, _, _, _) in PROF_KINDS.items():
+            tot, n, fl, by = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+            check(L.uvit_engine_profile_read_kind(engine.h, kind, C.byref(tot), C.byref(n), C.byref(fl), C.byref(by)), "profile read")
+            if n.value:
+                res[name] = (tot.value / n.value, n.value, fl.value, by.value)
+        return res
+    sched = read_kinds()           # inside the timed region (two-stream schedule unless --single-stream)
+    alone = None
     if not a.single_stream and not a.no_alone:
-        # the same kernel alone on the GPU: a few extra single-stream steps right after the timed region
+        # the same kernels with the GPU to themselves: a few extra single-stream steps right after the timed region
         check(L.uvit_engine_set_streams(engine.h, 0), "set_streams")
         check(L.uvit_engine_profile(engine.h, 1, 4096), "profile on")
         for i in range(3):
             step(a.warmup + a.steps + i)
         fence()
         check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
-        check(L.uvit_engine_profile_read(engine.h, C.byref(tot), C.byref(n), C.byref(fl)), "profile read")
-        alone_ms = tot.value / max(n.value, 1)
+        alone = read_kinds()
         check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
+    # the step without the masked-row bound (every row through the last block's MLP): img/s beside `value`, same run
+    all_rows_value = None
+    if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone:
+        keep = feed["mask_rows"]
+        feed["mask_rows"] = 0
+        for i in range(2):
+            step(a.warmup + a.steps + 10 + i)
+        fence(); t1 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + a.steps + 12 + i)
+        fence()
+        all_rows_value = round(a.batch * a.steps / (time.perf_counter() - t1), 2)
+        feed["mask_rows"] = keep
     stats = torch.zeros(2).pin_memory()
     check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
     staging = None
@@ -306,9 +360,36 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = a.batch * world * a.steps / dt
-        # headline: the dominant kernel's launches INSIDE the timed region (HIP events on the stream it is launched on).  In
-        # the default two-stream schedule other kernels share the CUs with it there; "alone" is the same kernel by itself.
-        achieved = flops / (in_ms * 1e-3) / 1e12 if in_n else 0.0
+        gflop = GFLOP_BY_MODEL.get(a.model, GFLOP_PER_IMAGE)
+        # FLOPs the step really executes: with the masked-row bound the last block's MLP (teacher forward; student forward, two
+        # dgrads, two wgrads = 8 GEMMs of 2 rows C Hd) skips the rows that feed neither the loss nor the targets
+        M_rows, Cd, Hdd = a.batch * 197, model.embed_dim, 4 * model.embed_dim
+        skipped = 16.0 * max(M_rows - feed["mask_rows"], 0) * Cd * Hdd / a.batch / 1e9 if (feed["mask_rows"] and not stochastic) else 0.0
+        traffic = pmc_traffic()
+        rp = rocprof_avg_us()
+
+        def entry(name, src):
+            ms_, n_, fl_, by_ = src[name]
+            d = {"avg_launch_ms": round(ms_, 4), "launches": n_, "achieved_tflops": round(fl_ / (ms_ * 1e-3) / 1e12, 1),
+                 "frac_mfma": round(fl_ / (ms_ * 1e-3) / PEAK_BF16, 4), "flops_per_launch": fl_, "algorithmic_bytes": int(by_),
+                 "frac_hbm_algorithmic": round(by_ / (ms_ * 1e-3) / PEAK_HBM, 4)}
+            t = traffic.get(name)
+            if t:
+                d["traffic"] = t["fetch"] + t["write"]
+                d["traffic_over_algorithmic"] = round((t["fetch"] + t["write"]) / by_, 3)
+                d["traffic_detail"] = t
+            return d
+        best = alone if alone else sched              # single-stream numbers are the ones rocprofv3's summary can reproduce
+        fam = [k for k in ("proj", "fc2") if k in best]            # largest kernel by time: the residual-epilogue instantiation
+        fam_ms = sum(best[k][0] * best[k][1] for k in fam)
+        fam_fl = sum(best[k][2] * best[k][1] for k in fam)
+        fam_by = sum(best[k][3] * best[k][1] for k in fam)
+        fam_n = sum(best[k][1] for k in fam)
+        achieved = fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms else 0.0
+        sch_ms = sum(sched[k][0] * sched[k][1] for k in fam if k in sched)
+        sch_fl = sum(sched[k][2] * sched[k][1] for k in fam if k in sched)
+        fam_traffic = (sum((traffic[k]["fetch"] + traffic[k]["write"]) * best[k][1] for k in fam) // max(fam_n, 1)) if all(k in traffic for k in fam) and fam else None
+        rp_key = next((k for k in rp if k.startswith("void gemm_nt256_kernel<3, 5, false>")), None)
         out = {
             "metric": "pretrain images/sec (ViT-B/16 224, bs=128/GPU)", "value": round(value, 2), "unit": "img/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
@@ -317,24 +398,36 @@ def main():
                                    f"bs={a.batch}/GPU, 224x224 synthetic, target_layers=upper half, attn_drop 0.05, drop_path 0.25, clip 3.0, "
                                    "AdamW, EMA 0.9998",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "model": a.model, "step_mfma_frac": round(value / world * GFLOP_BY_MODEL.get(a.model, GFLOP_PER_IMAGE) * 1e9 / PEAK_BF16, 4),
+                       "model": a.model, "step_mfma_frac": round(value / world * gflop * 1e9 / PEAK_BF16, 4),
+                       "executed_flops_frac": round(value / world * (gflop - skipped) * 1e9 / PEAK_BF16, 4),
+                       "executed_gflop_per_image": round(gflop - skipped, 3),
+                       "value_all_rows": all_rows_value,
                        "final_loss": round(float(stats[0]), 5),
                        "last_block_mlp_rows": (f"{feed['mask_rows']} masked rows of {a.batch * 197} (host-side bound; same results as all rows)"
                                                if feed["mask_rows"] and not stochastic else "all"),
-                       "step_mfma_frac_note": "algorithmic FLOPs of the reference's step (SURVEY 8d) / time / peak"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<EPI_GELU | EPI_GELU_DG> (fc1: M=25216 N=3072 K=768, bf16 MFMA, fused bias+GELU; the student launch also stores gelu'(h))",
+                       "step_mfma_frac_note": "step_mfma_frac = algorithmic FLOPs of the reference's step (SURVEY 8d) / time / peak; executed_flops_frac "
+                                              "counts only the FLOPs this step runs (the last block's MLP skips unmasked rows); value_all_rows = img/s "
+                                              "with every row through that MLP, same process"},
+            "roofline": {"bound": "mfma",
+                         "kernel": "gemm_nt256_kernel<EPI_RESID, 320x256 tile> -- the largest kernel by time of the single-stream rocprofv3 summary: "
+                                   "the Linears with the LayerScale x DropPath x fp32-residual epilogue (attention proj, K=768, and MLP fc2, K=3072; "
+                                   f"M={M_rows} N={Cd}), {fam_n} timed launches; per-shape figures and the fc1 launches under by_instantiation",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / PEAK_BF16, 4), "traffic": pmc_traffic_bytes(),
-                         "traffic_source": "profiles/round3_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_run.sh): 2 x FETCH_SIZE + WRITE_SIZE per launch",
-                         "algorithmic_bytes": ALGO_BYTES, "launches_timed": in_n, "avg_launch_ms": round(in_ms, 4),
-                         "flops_per_launch": flops,
-                         "measured": "HIP events on the launch stream over the timed region (" +
-                                     ("single stream: the kernel has the GPU to itself)" if a.single_stream else
-                                      "two-stream schedule: other kernels share the CUs with it)"),
-                         "alone": None if alone_ms is None else {
-                             "avg_launch_ms": round(alone_ms, 4), "achieved": round(flops / (alone_ms * 1e-3) / 1e12, 2),
-                             "frac": round(flops / (alone_ms * 1e-3) / PEAK_BF16, 4),
-                             "measured": "3 single-stream steps right after the timed region (kernel alone on the GPU)"}},
+                         "frac": round(achieved * 1e12 / PEAK_BF16, 4),
+                         "avg_launch_ms": round(fam_ms / max(fam_n, 1), 4), "launches_timed": fam_n,
+                         "algorithmic_bytes": int(fam_by / max(fam_n, 1)), "traffic": fam_traffic,
+                         "traffic_source": "profiles/round4_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-stream run, tools/pmc_run.sh; "
+                                           "2 x FETCH_SIZE + WRITE_SIZE per launch, per shape; FETCH_SIZE counts Infinity-Cache hits, dram_read "
+                                           "(TCC_EA0_RDREQ_DRAM, where collected) is the part that reached HBM)",
+                         "measured": ("HIP events on the launch stream over the timed region, single stream (the kernel has the GPU to itself)" if a.single_stream or not alone else
+                                      "HIP events on the launch stream over 3 single-stream steps right after the timed region (the kernel has the GPU to "
+                                      "itself: what rocprofv3's per-kernel average of a single-stream run reproduces); in_schedule = the same launches "
+                                      "inside the timed region, where the second stream's kernels share the CUs"),
+                         "rocprof_check": {"file": "profiles/round4_step_kernel_stats_singlestream.txt", "avg_launch_us": rp.get(rp_key) if rp_key else None},
+                         "in_schedule": None if not sch_ms else {"avg_launch_ms": round(sch_ms / sum(sched[k][1] for k in fam if k in sched), 4),
+                                                                 "achieved": round(sch_fl / (sch_ms * 1e-3) / 1e12, 2),
+                                                                 "frac": round(sch_fl / (sch_ms * 1e-3) / PEAK_BF16, 4)},
+                         "by_instantiation": {k: entry(k, best) for k in PROF_KINDS if k in best}},
             "rccl_ranks": rccl["allreduce_ones"] if rccl else 1,      # sum of one `1` per rank through an RCCL all-reduce
             "rccl": rccl,
             "rccl_max_channels": rccl_channels,

@@ -182,6 +182,11 @@ int uvit_engine_set_streams(uvit_engine* e, int dual);
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */
 int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
 int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
+/* The brackets by kind: 0 = fc1 of the teacher (bias + GELU), 1 = fc1 of the student (also stores GELU'), 2 = attention proj and
+ * 3 = fc2 (both: bias, LayerScale, DropPath, fp32 residual epilogue), -1 = kinds 0 and 1 together.  bytes_per_launch (nullable) =
+ * the launch's algorithmic HBM bytes (operands read once, results written once). */
+int uvit_engine_profile_read_kind(uvit_engine* e, int kind, double* total_ms, int* launches, double* flops_per_launch,
+                                  double* bytes_per_launch);
 /* enqueues the copy of 8 floats {loss, grad_norm, -, -, std_loss0 (the `loss_var0` meter), ...} of the last step into (pinned) host memory behind the step's kernels and returns:
  * the caller reads them after an event it records on `stream` has completed (engine_for_cyclical.py:164,186
  * sync twice per step instead).  A step whose loss or gradient norm is not finite leaves the weights untouched, and so

@@ -169,7 +169,11 @@ def train_step(params, ema, m, v, cfg, hp: vo.StepHParams, samples, mask, step, 
     """engine_for_cyclical.py:45-186 with stochastic=True."""
     with torch.no_grad():
         tm, tc = forward(ema, cfg, samples, None, True, hp.layer_results)
-        targets, cov_targets = vo.build_targets(tm, mask, hp), vo.build_targets(tc, mask, hp)
+        # the batch- / instance-norm variants act on the MEAN targets only (engine_for_cyclical.py:93-118); the covariance targets
+        # (:73-86) know `target_layer_norm_last` and `post_target_layer_norm` and nothing else
+        import dataclasses
+        hp_cov = dataclasses.replace(hp, target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False)
+        targets, cov_targets = vo.build_targets(tm, mask, hp), vo.build_targets(tc, mask, hp_cov)
     leaves = {k: t.detach().clone().requires_grad_(True) for k, t in params.items()}
     out, cov_out = forward(leaves, cfg, samples, mask, False, None, drop)
     # loss = loss_cyc + std_loss0 * var_w0 + loss_stochastic (engine_for_cyclical.py:130-139, 161): the variance term acts on the MEAN outputs

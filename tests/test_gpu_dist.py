@@ -345,3 +345,46 @@ def test_two_stream_large_bs64_step_properties():
                                    vo.VitConfig(embed_dim=1024, depth=24, num_heads=16, init_values=1e-4), B=64, img=224, n_patches=196,
                                    n_mask=120, target_layers=list(range(12, 24)), two_stream=True, lam=1e-5, tag="dlfull")
     print("two-stream ViT-L bs=64 step:", {k: st[k] for k in ("loss", "grad_norm")})
+
+
+DIST_TNORM = {"bn": dict(target_batch_norm=True, target_layer_norm_last=True, post_target_layer_norm=True),
+              "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False,
+                                post_target_instance_norm=True, post_target_layer_norm=True)}
+
+
+@pytest.mark.parametrize("case", list(DIST_TNORM))
+def test_two_stream_step_with_target_norm_variants(golden_dir, case):
+    """`--stochastic` with `--target_batch_norm` / `--target_instance_norm` / `--no_target_layer_norm_last` /
+    `--post_target_instance_norm` (engine_for_cyclical.py:93-118 on the mean targets, :73-86 for the covariance targets): one step of
+    the HIP path (dense builder for stream 0, masked-row builder for stream 1) against the reference's numbers and the oracle."""
+    from uncertainty_vit_amd import engine_for_cyclical as eng, optim_factory, utils
+    fx = np.load(os.path.join(golden_dir, "dist_target_norms.npz"))
+    img, dim, depth, heads, B, n_mask, _ = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    model, sd0 = dist_model(cfg)
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
+    ema = utils.ModelEmaV2(model, decay=0.9998)
+    opt = optim_factory.create_optimizer(A(), model)
+    x, mask = closed_form_images("dtnorm", B, img), torch.from_numpy(fx["mask"])
+    fl = dict(target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False)
+    fl.update(DIST_TNORM[case])
+    st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, [1, 2], [((x.cuda(), mask.cuda()), torch.zeros(1))], opt, torch.device("cuda"), 0,
+                             utils.NativeScalerWithGradNormCount(), max_norm=3.0, l1_beta=2.0, start_steps=0, layer_results="end",
+                             loss_scale=-1, stochastic=True, lambda_pretraining=1e-2, **fl)
+    assert st["loss"] == pytest.approx(float(fx[f"{case}/loss"]), rel=5e-3)
+    assert st["grad_norm"] == pytest.approx(float(fx[f"{case}/grad_norm"]), rel=3e-2)
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for n in entries(fx, f"{case}/grad"):
+        key = f"{case}/grad/{n}/full"
+        if key in fx:
+            g, r = grads[n].float().cpu().double(), torch.from_numpy(np.asarray(fx[key])).double()
+            assert (g - r).norm() <= 4e-2 * r.norm(), (n, float((g - r).norm() / r.norm()))
+    p = {k: v.clone() for k, v in sd0.items()}
+    e = {k: v.clone() for k, v in sd0.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    ref, _, _, _ = vd.train_step(p, e, m, v, cfg, vo.StepHParams(target_layers=(1, 2), **DIST_TNORM[case]), x, mask, 1, lam=1e-2)
+    assert st["loss"] == pytest.approx(ref.loss, rel=5e-3)
+    assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)

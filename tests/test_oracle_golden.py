@@ -295,3 +295,28 @@ def test_batch_and_instance_norm_target_variants(golden_dir, case):
     assert res.grad_norm == pytest.approx(float(fx[f"{case}/grad_norm"]), rel=2e-3)
     for n in entries(fx, f"{case}/grad"):
         check_entry(fx, f"{case}/grad/{n}", res.grads[n], 2e-3, 2e-7)
+
+
+DIST_TNORM = {"bn": dict(target_batch_norm=True, target_layer_norm_last=True, post_target_layer_norm=True),
+              "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False,
+                                post_target_instance_norm=True, post_target_layer_norm=True)}
+
+
+@pytest.mark.parametrize("case", list(DIST_TNORM))
+def test_two_stream_step_with_target_norm_variants(golden_dir, case):
+    """engine_for_cyclical.py:93-118 in a `stochastic=True` step: the batch- / instance-norm variants act on the MEAN targets, the
+    covariance targets (:73-86) follow the two layer-norm flags only.  One oracle step per flag combination against the reference."""
+    from oracle import vit_oracle_dist as vd
+    fx = np.load(os.path.join(golden_dir, "dist_target_norms.npz"))
+    img, dim, depth, heads, B, n_mask, _ = [int(v) for v in fx["cfg"]]
+    cfg = vo.VitConfig(img_size=img, embed_dim=dim, depth=depth, num_heads=heads, init_values=0.1)
+    p = closed_form_state(vd.param_shapes(cfg), gamma=0.1)
+    ema = {k: t.clone() for k, t in p.items()}
+    m = {k: torch.zeros_like(t) for k, t in p.items()}
+    v = {k: torch.zeros_like(t) for k, t in p.items()}
+    hp = vo.StepHParams(target_layers=(1, 2), **DIST_TNORM[case])
+    res, _, _, _ = vd.train_step(p, ema, m, v, cfg, hp, closed_form_images("dtnorm", B, img), torch.from_numpy(fx["mask"]), 1, lam=1e-2)
+    assert res.loss == pytest.approx(float(fx[f"{case}/loss"]), rel=2e-4)
+    assert res.grad_norm == pytest.approx(float(fx[f"{case}/grad_norm"]), rel=2e-3)
+    for n in entries(fx, f"{case}/grad"):
+        check_entry(fx, f"{case}/grad/{n}", res.grads[n], 2e-3, 2e-7)

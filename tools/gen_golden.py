@@ -257,6 +257,48 @@ def gen_dist_case(mc, eng, tag, img, dim, depth, heads, init_values, B, n_mask, 
     print("wrote dist", tag, "loss", losses, "gnorm", gnorms)
 
 
+DIST_TARGET_NORM_CASES = {   # two-stream step with the mean-target variants of engine_for_cyclical.py:93-118 (covariance targets :73-86)
+    "bn":        dict(target_batch_norm=True, target_instance_norm=False, target_layer_norm_last=True, post_target_instance_norm=False, post_target_layer_norm=True),
+    "bn_in_pin": dict(target_batch_norm=True, target_instance_norm=True, target_layer_norm_last=False, post_target_instance_norm=True, post_target_layer_norm=True),
+}
+
+
+def gen_dist_target_norm_cases(mc, eng):
+    """`train_one_epoch(stochastic=True)` with the batch- / instance-norm target variants: the reference applies them to the MEAN
+    targets (engine_for_cyclical.py:93-118) while the covariance targets (:73-86) only follow the two layer-norm flags.  One reference
+    step per flag combination on the tiny two-stream model: loss, grad-norm and a few gradients."""
+    import modeling_cyclical_dist as mcd
+    import optim_factory
+    import timm.utils as U
+    img, dim, depth, heads, B, n_mask = 48, 128, 3, 2, 5, 4
+    out = {"cfg": np.array([img, dim, depth, heads, B, n_mask, 1], dtype=np.int64), "cases": np.array(list(DIST_TARGET_NORM_CASES)),
+           "init_values": np.float64(0.1)}
+    x, mask = closed_form_images("dtnorm", B, img), exact_masks(B, 9, n_mask, 950)
+    out["mask"] = mask.numpy()
+    for name, fl in DIST_TARGET_NORM_CASES.items():
+        model = mcd.DistVisionTransformerForCyclicalTraining(
+            img_size=img, patch_size=16, embed_dim=dim, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), init_values=0.1, use_shared_rel_pos_bias=True,
+            use_abs_pos_emb=False, drop_path_rate=0.0, attn_drop_rate=0.0)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype == torch.float32}
+        model.load_state_dict(closed_form_state(shapes, gamma=0.1), strict=False)
+        model.train()
+        ema = U.ModelEmaV2(model, decay=0.9998)
+        args = SimpleNamespace(opt="adamw", lr=2e-3, weight_decay=0.05, opt_eps=1e-8, opt_betas=(0.9, 0.999), momentum=0.9)
+        opt = optim_factory.create_optimizer(args, model)
+        scaler = ref_harness.HarnessScaler()
+        st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, [1, 2], [((x, mask), torch.zeros(1))], opt, torch.device("cpu"), 0, scaler,
+                                 max_norm=3.0, l1_beta=2.0, start_steps=0, layer_results="end", loss_scale=-1, stochastic=True,
+                                 lambda_pretraining=1e-2, **fl)
+        out[f"{name}/loss"], out[f"{name}/grad_norm"] = np.float64(st["loss"]), np.float64(float(st["grad_norm"]))
+        pn = [n for n, _ in model.named_parameters()]
+        grads = {n: g for n, g in zip(pn, scaler.grads) if g is not None}
+        for k in ("lm_head.weight", "cov_lm_head.weight", "blocks.2.mlp.fc2.weight", "blocks.0.attn.qkv.weight", "norm.weight"):
+            put(out, f"{name}/grad/{k}", grads[k])
+        print("dist target-norm case", name, "loss", st["loss"], "gnorm", float(st["grad_norm"]))
+    np.savez_compressed(os.path.join(OUT, "dist_target_norms.npz"), **out)
+
+
 def gen_loss_curve(mc, eng):
     img, dim, depth, heads, B, n_mask = 48, 128, 2, 2, 4, 5
     model = build(mc, img, dim, depth, heads, 0.1)
@@ -431,6 +473,8 @@ def main():
         gen_vitb_spot(mc)
     if a.only in (None, "tnorm"):
         gen_target_norm_cases(mc, eng)
+    if a.only in (None, "dtnorm"):
+        gen_dist_target_norm_cases(mc, eng)
     if a.only in (None, "abspos"):
         gen_abs_pos_case(mc, eng)
     if a.only in (None, "flags"):

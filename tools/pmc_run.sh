@@ -9,11 +9,18 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/${tag}
 mkdir -p $out
 cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
+# optional third / fourth pass (PMC_EXTRA="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum", when `rocprofv3 -L` lists them): the requests that
+# reach HBM itself -- FETCH_SIZE / WRITE_SIZE count the L2's fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM)
+for c in FETCH_SIZE WRITE_SIZE $PMC_EXTRA; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-input-staging --single-stream --model $model > $out/$c.log 2>&1 || { echo "pmc pass $c failed"; tail -5 $out/$c.log; exit 1; }
 done
 cd $root
-for k in "gemm_nt256_kernel<2, 4" "gemm_nt256_kernel<8, 4" "gemm_nt256_kernel<9, 4" "gemm_ntr_kernel<3, 10>" "gemm_nt256_kernel<1, 4" "gemm_nt256_kernel<0, 4" "gemm_nt256_kernel<0, 5" "gemm_nt_kernel<" "gemm_tn256_group" attn_fwd attn_bwd_fused attn_dbias_reduce attn2_fwd attn2_bwd_q attn2_bwd_kv ln_bwd ln_fwd adamw; do
+# one instantiation, two shapes in a fixed rotation (single-stream run): proj, fc2, proj, fc2, ...
+for c in FETCH_SIZE WRITE_SIZE $PMC_EXTRA; do
+  python tools/pmc_summary.py $out/$c "gemm_nt256_kernel<3, 5" --alternate 2 proj,fc2 | sed "s/^.*counter_collection.csv: /$c: /"
+done | tee $out/summary_resid.txt
+for k in "gemm_nt256_kernel<2, 4" "gemm_nt256_kernel<8, 4" "gemm_nt256_kernel<9, 4" "gemm_ntr_kernel<3, 10>" "gemm_nt256_kernel<1, 4" "gemm_nt256_kernel<0, 4" "gemm_nt256_kernel<0, 5" "gemm_nt_kernel<" "gemm_tn256_group" attn_fwd attn_bwd_fused attn_dbias_reduce attn2_fwd attn2_bwd_fused attn2_dbias_reduce ln_bwd ln_fwd adamw; do
   python tools/pmc_summary.py $out/FETCH_SIZE "$k" | sed 's/^.*counter_collection.csv: /fetch: /'
   python tools/pmc_summary.py $out/WRITE_SIZE "$k" | sed 's/^.*counter_collection.csv: /write: /'
+  for c in $PMC_EXTRA; do python tools/pmc_summary.py $out/$c "$k" | sed "s/^.*counter_collection.csv: /$c: /"; done
 done | tee $out/summary.txt

@@ -19,7 +19,7 @@ python3 - <<PY | tee $out/summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 tags = ("gemm_tn256_group", "gemm_nt256_kernel<3, 5", "gemm_nt256_kernel<0, 5", "gemm_nt256_kernel<1, 4", "gemm_nt256_kernel<8, 4", "gemm_nt256_kernel<9, 4",
-        "gemm_nt256_kernel<2, 4", "attn_bwd_fused", "attn_fwd", "ln_bwd", "ln_fwd")
+        "gemm_nt256_kernel<2, 4", "attn2_bwd_fused", "attn2_fwd", "attn_bwd_fused", "attn_fwd", "ln_bwd", "ln_fwd")
 for f in glob.glob("$out/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
@@ -33,7 +33,8 @@ for tag in tags:
     g = lambda c: sum(d[c]) / len(d[c]) if c in d else float("nan")
     for c, v in sorted(d.items()):
         print(f"   {c:28s} mean {sum(v)/len(v):16.1f}  ({len(v)} dispatches)")
-    # SQ counters are summed over the 8 XCDs' SQs; per-SIMD-cycle shares against SQ_BUSY_CYCLES x 4 SIMDs... report simple ratios
-    print(f"   -> MFMA busy / (BUSY_CYCLES x 4): {g('SQ_VALU_MFMA_BUSY_CYCLES') / (4 * g('SQ_BUSY_CYCLES')):.3f}   LDS active / BUSY: {g('SQ_ACTIVE_INST_LDS') / g('SQ_BUSY_CYCLES'):.3f}"
+    # MFMA utilisation in [0, 1]: SQ_VALU_MFMA_BUSY_CYCLES is summed over every SIMD of the chip (256 CUs x 4), GRBM_GUI_ACTIVE over the
+    # 8 XCDs, so the chip's SIMD-cycles of the dispatch are GRBM_GUI_ACTIVE / 8 x 1024 = GRBM_GUI_ACTIVE x 128
+    print(f"   -> MFMA utilisation = MFMA_BUSY / (GRBM_GUI_ACTIVE x 128): {g('SQ_VALU_MFMA_BUSY_CYCLES') / (128 * g('GRBM_GUI_ACTIVE')):.3f}   LDS active / BUSY: {g('SQ_ACTIVE_INST_LDS') / g('SQ_BUSY_CYCLES'):.3f}"
           f"   bank conflict / LDS idx active: {g('SQ_LDS_BANK_CONFLICT') / max(g('SQ_LDS_IDX_ACTIVE'), 1):.3f}   wait_any / wave_cycles: {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f}")
 PY

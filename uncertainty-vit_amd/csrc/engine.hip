@@ -176,6 +176,7 @@ struct uvit_engine {
     // optional HIP-event bracketing of the dominant kernel (fc1 GEMM, EPI_GELU) for bench.py's roofline
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
+    std::vector<int> prof_kind;        // per pair: UVIT_PROF_* (which Linear of the block the bracket holds)
     size_t prof_used = 0;
     // stacked-row helpers
     size_t rows_all() const { return (size_t)(S - 1) * Mpad + M; }      // rows a stacked row-wise op covers
@@ -411,6 +412,7 @@ extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches)
     if (!e) return UVIT_ERR_ARG;
     if (enable && e->prof_ev.empty()) {
         e->prof_ev.resize((size_t)(max_launches > 0 ? max_launches : 4096) * 2);
+        e->prof_kind.assign(e->prof_ev.size() / 2, -1);
         for (auto& ev : e->prof_ev) if (hipEventCreate(&ev) != hipSuccess) return UVIT_ERR_LAUNCH;
     }
     e->prof_on = enable != 0;
@@ -418,17 +420,41 @@ extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches)
     return UVIT_OK;
 }
 
-extern "C" int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch) {
-    if (!e || !total_ms || !launches) return UVIT_ERR_ARG;
+// kinds of bracketed launches (full-size forward Linears of a block; the bench line's roofline block names them)
+enum { UVIT_PROF_FC1_T = 0, UVIT_PROF_FC1_S = 1, UVIT_PROF_PROJ = 2, UVIT_PROF_FC2 = 3, UVIT_PROF_KINDS = 4 };
+
+// kind < 0: the two fc1 kinds together (the round-1 contract of uvit_engine_profile_read)
+extern "C" int uvit_engine_profile_read_kind(uvit_engine* e, int kind, double* total_ms, int* launches, double* flops_per_launch,
+                                             double* bytes_per_launch) {
+    if (!e || !total_ms || !launches || kind >= UVIT_PROF_KINDS) return UVIT_ERR_ARG;
     double t = 0.0; int n = 0;
     for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+        const int k = e->prof_kind[i / 2];
+        if (kind < 0 ? (k != UVIT_PROF_FC1_T && k != UVIT_PROF_FC1_S) : k != kind) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) != hipSuccess) return UVIT_ERR_LAUNCH;
         t += ms; ++n;
     }
     *total_ms = t; *launches = n;
-    if (flops_per_launch) *flops_per_launch = 2.0 * (double)e->cur_B * e->N * (double)e->Hd * e->C;
+    // algorithmic work of ONE launch: rows of one stream for proj / fc2 (a launch per stream), the stacked rows for fc1
+    const double M1 = (double)e->cur_B * e->N, Mall = (double)(e->S - 1) * e->Mpad + M1, C = e->C, Hd = e->Hd;
+    double fl = 0.0, by = 0.0;
+    if (kind < 0 || kind == UVIT_PROF_FC1_T || kind == UVIT_PROF_FC1_S) {
+        fl = 2.0 * Mall * Hd * C;
+        by = 2.0 * (Mall * C + Hd * C + Mall * Hd * (kind == UVIT_PROF_FC1_T ? 1.0 : kind == UVIT_PROF_FC1_S ? 2.0 : 1.5));
+    } else if (kind == UVIT_PROF_PROJ) {
+        fl = 2.0 * M1 * C * C;            // bf16 A + W, fp32 residual in and stream out (+ the student's saved bf16 branch output: not counted)
+        by = 2.0 * (M1 * C + C * C) + 8.0 * M1 * C;
+    } else {
+        fl = 2.0 * M1 * C * Hd;
+        by = 2.0 * (M1 * Hd + C * Hd) + 8.0 * M1 * C;
+    }
+    if (flops_per_launch) *flops_per_launch = fl;
+    if (bytes_per_launch) *bytes_per_launch = by;
     return UVIT_OK;
+}
+extern "C" int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch) {
+    return uvit_engine_profile_read_kind(e, -1, total_ms, launches, flops_per_launch, nullptr);
 }
 
 extern "C" int uvit_engine_sync_shadows(uvit_engine* e, int which, uvit_stream stream) {
@@ -480,24 +506,35 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         CHECK(uvit_attn2_fwd_launch(a.qkv, a.qkv + Mp * 3 * C, biasP, a.attn, a.attn + Mp * C, a.lse, Bc, e->H, e->N, e->NP, 0.125f,
                                     pdrop, seed, (uint32_t)l, s));
     }
+    // optional HIP-event brackets around the block's full-size forward Linears (bench.py's roofline block)
+    auto prof_begin = [&](int kind) -> bool {
+        if (!(e->prof_on && e->prof_used + 2 <= e->prof_ev.size())) return false;
+        e->prof_kind[e->prof_used / 2] = kind;
+        (void)hipEventRecord(e->prof_ev[e->prof_used], s);
+        return true;
+    };
+    auto prof_end = [&](bool on) { if (on) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; } };
     for (int st = 0; st < S; ++st) {
         GemmEpi p; p.out = x_mid + st * Mp * C; p.out2 = save ? a.projout + st * Mp * C : nullptr; p.bias = w.f + off_projb(o, st);
         p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
+        const bool pp = prof_begin(UVIT_PROF_PROJ);
         CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
+        prof_end(pp);
     }
     if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
     else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
-    const bool prof = R == 0 && e->prof_on && e->prof_used + 2 <= e->prof_ev.size();    // (only full-size fc1 launches are timed)
-    if (prof) (void)hipEventRecord(e->prof_ev[e->prof_used], s);
+    const bool prof = R == 0 && prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T);    // (only full-size launches are timed)
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
     CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, R > 0 ? R : Mall, Hd, C, C, C, &f1, s));
-    if (prof) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], s); e->prof_used += 2; }
+    prof_end(prof);
     for (int st = 0; st < S; ++st) {
         GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
         f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
         if (R > 0) { f2.rowmap = e->rowidx; f2.rowcount = e->count; }
+        const bool pf2 = R == 0 && prof_begin(UVIT_PROF_FC2);
         CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, R > 0 ? R : M, C, Hd, Hd, Hd, &f2, s));
+        prof_end(pf2);
     }
     return UVIT_OK;
 }
@@ -549,15 +586,18 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
             // the teacher's last block feeds nothing but the target rows: with a masked-row bound its MLP runs on those rows only
             const int Rt = (l == e->cfg.depth - 1 && !dense) ? e->compact_R : 0;
             CHECK(forward_layer(e, w, l, xin, e->tXM, xout, e->tacts, false, biasP, false, 0.f, 0, Bc, s, Rt));
-            if (dense && (e->S != 1 || Bc != e->B)) return UVIT_ERR_ARG;
+            if (dense && Bc != e->B) return UVIT_ERR_ARG;
             for (int k = 0; k < hp_targets->n_target_layers; ++k) {
                 if (hp_targets->target_layers[k] != l) continue;
                 const float* sub = hp_targets->layer_results_fc ? e->tXM : nullptr;     // --layer_results fc: x_out - x_mid
-                if (!dense) {
-                    for (int st = 0; st < e->S; ++st)
-                        CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
-                                                       Bc * e->P, e->C, 1e-5f, s, sub ? sub + (size_t)st * e->Mpad * e->C : nullptr));
-                } else {
+                // Stream 0 (the only one of the base model; the MEAN targets of a stochastic step, engine_for_cyclical.py:93-118)
+                // takes the dense builder when a batch- / instance-norm variant is on; the covariance targets (:73-86) only know
+                // `target_layer_norm_last` and `post_target_layer_norm` and always go through the masked-row builder.
+                for (int st = dense ? 1 : 0; st < e->S; ++st)
+                    CHECK(uvit_target_accum_launch(xout + (size_t)st * e->Mpad * e->C, e->rowidx, e->count, e->targets[st], n_t == 0,
+                                                   Bc * e->P, e->C, 1e-5f, s, sub ? sub + (size_t)st * e->Mpad * e->C : nullptr,
+                                                   hp_targets->target_layer_norm_last ? 1 : 0));
+                if (dense) {
                     // all patch tokens of this layer -> [batch norm] -> [instance norm] -> [LayerNorm] -> accumulate
                     CHECK(uvit_gather_patch_rows_launch(xout, sub, e->dense_v, Bc, e->P, e->C, s));
                     if (hp_targets->target_batch_norm) CHECK(uvit_colnorm_launch(e->dense_v, 1, Bc * e->P, e->C, 1e-5f, s));
@@ -574,10 +614,9 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
         if (n_t != hp_targets->n_target_layers) return UVIT_ERR_ARG;     // an index outside [0, depth) reached the C ABI
         const bool dense = hp_targets->target_batch_norm || hp_targets->target_instance_norm ||
                            hp_targets->post_target_instance_norm || !hp_targets->target_layer_norm_last;
-        if (!dense) {
-            for (int st = 0; st < e->S; ++st)
-                CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
-        } else {
+        for (int st = dense ? 1 : 0; st < e->S; ++st)
+            CHECK(uvit_target_finalize_launch(e->targets[st], e->count, n_t, hp_targets->post_target_layer_norm, Bc * e->P, e->C, 1e-5f, s));
+        if (dense) {
             const bool pin = hp_targets->post_target_instance_norm != 0;
             CHECK(uvit_target_finalize_launch(e->dense_acc, e->idcount, n_t, hp_targets->post_target_layer_norm && !pin, Bc * e->P, e->C, 1e-5f, s));
             if (pin) {

@@ -228,7 +228,7 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
 template <int NV>
 __global__ __launch_bounds__(LN_WAVES * 64)
 void target_accum_kernel(const float* __restrict__ x, const float* __restrict__ sub, const int* __restrict__ rowidx,
-                         const int* __restrict__ count, float* __restrict__ acc, int first, int Mmax, int C, float eps) {
+                         const int* __restrict__ count, float* __restrict__ acc, int first, int Mmax, int C, float eps, int ln) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= Mmax) return;
@@ -248,8 +248,8 @@ void target_accum_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < NV; ++k) { r.v[k].x -= q.v[k].x; r.v[k].y -= q.v[k].y; r.v[k].z -= q.v[k].z; r.v[k].w -= q.v[k].w; }
     }
-    float mean, rstd;
-    row_stats(r, C, lane, eps, mean, rstd);
+    float mean = 0.f, rstd = 1.f;
+    if (ln) row_stats(r, C, lane, eps, mean, rstd);          // ln == 0 (--no_target_layer_norm_last): the rows are summed as they are
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
@@ -356,10 +356,10 @@ int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx
     return uvit_check_launch();
 }
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
-                             int C, float eps, hipStream_t s, const float* sub) {
+                             int C, float eps, hipStream_t s, const float* sub, int ln) {
     if (ln_shape_ok(Mmax, C)) return UVIT_ERR_SHAPE;
     LN_DISPATCH(target_accum_kernel, C, dim3((Mmax + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, sub, rowidx,
-                       count, acc, first, Mmax, C, eps);
+                       count, acc, first, Mmax, C, eps, ln);
     return uvit_check_launch();
 }
 int uvit_target_finalize_launch(float* acc, const int* count, int n_layers, int post_ln, int Mmax, int C, float eps,

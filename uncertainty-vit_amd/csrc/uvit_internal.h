@@ -107,7 +107,8 @@ int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* r
                                int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
 int uvit_reduce_replicas_launch(const float* rep, float* out, size_t n, int nrep, size_t stride, hipStream_t s);
 int uvit_target_accum_launch(const float* x, const int* rowidx, const int* count, float* acc, int first, int Mmax,
-                             int C, float eps, hipStream_t s, const float* sub = nullptr);   // sub: rows subtracted before the LayerNorm
+                             int C, float eps, hipStream_t s, const float* sub = nullptr,     // sub: rows subtracted before the LayerNorm
+                             int ln = 1);                                                   // ln = 0: no LayerNorm, the rows are summed as they are
 int uvit_variance_loss_launch(const float* out, const int* count, float w, float margin, float loss_scale, float* scratch,
                               float* loss, float* std_loss0_out, void* dout_bf16, int Mmax, int C, hipStream_t s);
 int uvit_gather_patch_rows_launch(const float* x, const float* sub, float* v, int B, int P, int C, hipStream_t s);

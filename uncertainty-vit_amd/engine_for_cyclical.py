@@ -241,14 +241,11 @@ def train_one_epoch(model: torch.nn.Module, model_ema: torch.nn.Module, ema_star
     model.train()
     net = _unwrap(model)
     teacher = model_ema.module
-    if stochastic and (layer_results != 'end' or dense_targets):
-        # the variance term (engine_for_cyclical.py:130-139,161) acts on the mean outputs in both models and IS native with the
-        # two-stream step; the batch- / instance-norm target variants that the reference applies to the MEAN targets of a
-        # stochastic step too (engine_for_cyclical.py:93-118; its covariance twin :73-86 has layer-norm targets only) are not
+    if stochastic and layer_results != 'end':
+        # the variance term (engine_for_cyclical.py:130-139,161) and, since round 4, the batch- / instance-norm target variants on the
+        # MEAN targets (:93-118; the covariance targets :73-86 only know the two layer-norm flags) are native with the two-stream step
         raise NotImplementedError("the two-stream step is native for layer_results='end' (modeling_cyclical_dist.py:136-139 collects "
-                                  "only 'end' results) and layer-norm targets; --target_batch_norm / --target_instance_norm / "
-                                  "--post_target_instance_norm / --no_target_layer_norm_last on the mean targets of a stochastic step "
-                                  "(engine_for_cyclical.py:93-118) are not built")
+                                  "only 'end' results)")
     if bool(stochastic) != bool(getattr(net, "_two_stream", False)):
         # the reference unpacks (mean, cov) pairs when stochastic (engine_for_cyclical.py:70,126): only the two-stream
         # model (dist_beit_base_patch16_224) returns them -- SURVEY.md F8

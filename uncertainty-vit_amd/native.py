@@ -114,6 +114,7 @@ _PROTOTYPES = {
     "uvit_engine_set_streams": (_i, [_vp, _i]),
     "uvit_engine_profile": (_i, [_vp, _i, _i]),
     "uvit_engine_profile_read": (_i, [_vp, _vp, _vp, _vp]),
+    "uvit_engine_profile_read_kind": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "uvit_op_gemm_nt": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "uvit_op_gemm_nt_tuned": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "uvit_op_gemm_tn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
