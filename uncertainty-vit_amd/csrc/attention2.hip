@@ -10,12 +10,11 @@
 // B_j = [m2_j | sqrt(c2_j)]; row terms r_i, c_j are fp32 side vectors.  cov_q/k/v arrive as
 // ELU(.)+1 (the QKV epilogue); the backward folds ELU'(x) = min(ELU(x)+1, 1) into its outputs.
 //
-// Same machinery as attention.hip: [224][64] bf16 LDS images (swizzled 128-B rows) read by rows
+// Same machinery as attention.hip: [208][64] bf16 LDS images (swizzled 128-B rows) read by rows
 // (ds_read_b128) and by columns (ds_read_b64_tr_b16), accumulator tiles reused as MFMA operands,
 // log2-unit scores (biasP = bias*log2e, -1e30 in padded key columns), pair-hash dropout.
-//   fwd     : images Bm, Bc (keys), V, CV;  the wave's queries in registers
-//   bwd q   : + dMean, dCov rows in registers -> dq, dcov_q, rel-pos-bias gradient slabs, delta
-//   bwd kv  : images Am, Ac (queries), dMean, dCov; the wave's keys in registers -> dk, dcov_k, dv, dcov_v
+//   fwd : 13 waves, one query tile each; images Bm, Bc (keys, transformed on the way in), V, CV (LDS-DMA)
+//   bwd : ONE fused kernel (round 4): query-side images Am, Ac, dMean, dCov whole, key-side rows in a 2-slot ring, 16-key steps
 #include <mutex>
 #include <type_traits>
 #include "common.h"
@@ -30,9 +29,6 @@
 #endif
 #define HD 64
 #define NT_MAX 13
-#define ROWS_PAD 224
-#define IMG_BYTES (ROWS_PAD * 128)
-#define W2_WAVES 7
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1e30f)
 
@@ -40,38 +36,6 @@ __device__ __forceinline__ int img_off2(int row, int chunk) { return row * 128 +
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 enum { TR_NONE = 0, TR_SIG = 1, TR_SQRT_SIG = 2 };
-
-// stage rows of a (tokens x 64) bf16 slice into a swizzled image with an elementwise transform; optionally
-// accumulate per-row side sums (sum of sig^2 for TR_SIG, sum of sig for TR_SQRT_SIG) into rowsum[] (LDS floats)
-template <int TR>
-__device__ __forceinline__ void load_image_tr(char* img, const bf16* src, size_t stride, int n_valid, float pre_scale,
-                                              float* rowsum, int tid, int nthreads) {
-    for (int idx = tid; idx < ROWS_PAD * 8; idx += nthreads) {
-        const int row = idx >> 3, chunk = idx & 7;
-        bf16x8 o;
-        float part = 0.f;
-        if (row < n_valid) {
-            const bf16x8 v = *(const bf16x8*)(src + (size_t)row * stride + chunk * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = bf2f(v[j]);
-                if constexpr (TR == TR_SIG) { x = sigm(x * pre_scale); part += x * x; }
-                else if constexpr (TR == TR_SQRT_SIG) { x = sigm(x); part += x; x = sqrtf(x); }
-                o[j] = f2bf(x);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(0.f);
-        }
-        *(bf16x8*)(img + img_off2(row, chunk)) = o;
-        if constexpr (TR != TR_NONE) {
-            if (rowsum) {          // 8 consecutive lanes hold one row's chunks
-                part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-                if (chunk == 0) atomicAdd(&rowsum[row], part);
-            }
-        }
-    }
-}
 
 __device__ __forceinline__ bf16x8 rowf(const char* img, int row, int chunk) { return *(const bf16x8*)(img + img_off2(row, chunk)); }
 
@@ -126,128 +90,187 @@ __device__ __forceinline__ TokFrags load_tok(const bf16* mean_row, const bf16* c
     return t;
 }
 
+__device__ __forceinline__ void dma_rows8_2(char* img, int rb, const bf16* src, size_t stride, int row0, int n_valid, int lane) {
+    const int row = row0 + 8 * rb + (lane >> 3);
+    const int chunk = (lane & 7) ^ (lane >> 3);
+    const int r = row < n_valid ? row : n_valid - 1;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)r * stride + chunk * 8), LDS_PTR(void, img + rb * 1024), 16, 0, 0);
+}
+// one 16-B chunk of a token row through the transform: returns the transformed chunk and this chunk's part of the row term
+template <int TR>
+__device__ __forceinline__ bf16x8 tr_chunk(const bf16x8 v, float pre_scale, float& part) {
+    bf16x8 o;
+    part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float x = bf2f(v[j]);
+        if constexpr (TR == TR_SIG) { x = sigm(x * pre_scale); part += x * x; }
+        else { x = sigm(x); part += x; x = sqrtf(x); }
+        o[j] = f2bf(x);
+    }
+    return o;
+}
+
 // ------------------------------------------------------------------------------------------
-// forward
+// forward (round 4: 13 waves, one query tile each, <= 128 VGPRs; was 7 waves x 2 tiles at ~200 VGPRs)
+//
+// One 13-wave workgroup per (batch, head).  The key-side operands B_m = sigmoid(k), B_c = sqrt(sigmoid(cov_k)) are transformed on
+// the way into their LDS images (4 chunk tasks per lane; the column term c_j leaves through 8-lane DPP sums, no LDS atomics); V and
+// cov_v arrive by LDS-DMA; the wave's own query operands A_m, A_c and the row term r_i are built in registers.  Scores of the
+// wave's 16 queries against all 13 key tiles stay in registers (52 values per lane, the bias rows are requested into them up
+// front), the softmax row is 2 shuffles, P and P^2 feed the two PV products straight from the accumulators.
 // ------------------------------------------------------------------------------------------
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(W2_WAVES * 64)
+#define FW2_WAVES 13
+#define FW2_ROWS (NT_MAX * 16)
+#define FW2_IMG (FW2_ROWS * 128)
+#define FW2_LDS (4 * FW2_IMG + FW2_ROWS * 4)
+
+template <bool HAS_BIAS, int NT_C>
+__global__ __launch_bounds__(FW2_WAVES * 64)
 void attn2_fwd_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ qkv_c, const float* __restrict__ biasP,
                       bf16* __restrict__ out_m, bf16* __restrict__ out_c, float* __restrict__ lse, int H, int N, int NP,
                       float scale, uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *bm = smem, *bc = smem + IMG_BYTES, *vimg = smem + 2 * IMG_BYTES, *cvimg = smem + 3 * IMG_BYTES;
-    float* cj = (float*)(smem + 4 * IMG_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char *bm = smem, *bc = smem + FW2_IMG, *vimg = smem + 2 * FW2_IMG, *cvimg = smem + 3 * FW2_IMG;
+    float* cj = (float*)(smem + 4 * FW2_IMG);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
     const bf16* base_m = qkv_m + (size_t)b * N * ld + h * HD;
     const bf16* base_c = qkv_c + (size_t)b * N * ld + h * HD;
-    for (int i = tid; i < ROWS_PAD; i += W2_WAVES * 64) cj[i] = 0.f;
-    __syncthreads();
-    load_image_tr<TR_SIG>(bm, base_m + C, ld, N, 1.0f, cj, tid, W2_WAVES * 64);
-    load_image_tr<TR_SQRT_SIG>(bc, base_c + C, ld, N, 1.0f, cj, tid, W2_WAVES * 64);
-    load_image_tr<TR_NONE>(vimg, base_m + 2 * C, ld, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-    load_image_tr<TR_NONE>(cvimg, base_c + 2 * C, ld, N, 1.0f, nullptr, tid, W2_WAVES * 64);
-    __syncthreads();
-    const int nt = (N + 15) >> 4, nt2 = (nt + 1) >> 1;
+    const int nt = NT_C ? NT_C : (N + 15) >> 4, nt2 = (nt + 1) >> 1;
+    const bool active = NT_C ? true : wave < nt;
+    const int q = wave * 16 + li, qr = q < N ? q : N - 1;
 
-    for (int qt = wave; qt < nt; qt += W2_WAVES) {
-        const int q = qt * 16 + li;
-        const int qr = q < N ? q : N - 1;
-        const TokFrags A = load_tok(base_m + (size_t)qr * ld, base_c + (size_t)qr * ld, g, scale);
-        const float ri = gsum4(A.side);
-        float s[NT_MAX][4];
-        // all bias rows of the tile are requested up front, into the registers that will hold the scores
-        if constexpr (HAS_BIAS) {
+    // ---- every global request first: V / CV by LDS-DMA, this wave's raw query rows, the raw key chunks of its 4 staging tasks
+    for (int p = wave; p < 2 * (FW2_ROWS / 8); p += FW2_WAVES) {
+        const int img = p & 1, rb = p >> 1;
+        if (rb * 8 >= nt * 16) continue;
+        dma_rows8_2(img ? cvimg : vimg, rb, (img ? base_c : base_m) + 2 * C, ld, 0, N, lane);
+    }
+    // staging tasks: task = wave + 13 j covers (tensor, 8-row block): 2 x 26 row blocks of 8 rows x 8 chunks
+    bf16x8 kraw[4];
 #pragma unroll
-            for (int t = 0; t < NT_MAX; ++t)
-                if (t < nt) {
-                    const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
-                    s[t][0] = bv.x; s[t][1] = bv.y; s[t][2] = bv.z; s[t][3] = bv.w;
-                }
+    for (int j = 0; j < 4; ++j) {
+        const int task = wave + FW2_WAVES * j, tens = task & 1, rb = task >> 1;
+        const int row = rb * 8 + (lane >> 3), rr = row < N ? row : N - 1;
+        kraw[j] = *(const bf16x8*)((tens ? base_c : base_m) + C + (size_t)rr * ld + (lane & 7) * 8);
+    }
+    TokFrags A;
+    float ri = 0.f;
+    if (active) {
+        A = load_tok(base_m + (size_t)qr * ld, base_c + (size_t)qr * ld, g, scale);
+        ri = gsum4(A.side);
+    }
+    for (int i = tid; i < FW2_ROWS; i += FW2_WAVES * 64) cj[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int task = wave + FW2_WAVES * j, tens = task & 1, rb = task >> 1;
+        const int row = rb * 8 + (lane >> 3), ch = lane & 7;
+        if (rb * 8 >= nt * 16) continue;
+        float part;
+        bf16x8 o = tens ? tr_chunk<TR_SQRT_SIG>(kraw[j], 1.0f, part) : tr_chunk<TR_SIG>(kraw[j], 1.0f, part);
+        if (row >= N) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(0.f);
         }
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < NT_MAX; ++t) {
-            if (t < nt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bm, t * 16 + li, kk * 4 + g), A.m[kk], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bc, t * 16 + li, kk * 4 + g), A.c[kk], a, 0, 0, 0);
-                }
-                const float4 cv4 = *(const float4*)(cj + t * 16 + 4 * g);
-                const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
-                float bb[4];
-                if constexpr (HAS_BIAS) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bb[r] = s[t][r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bb[r] = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = sigm(2.0f * a[r] - ri - cc[r]) * LOG2E + bb[r];     // sigmoid(-W) + bias, log2 units
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = 0.f;
-            }
-        }
-        mx = gmax4(mx);
-        float sum = 0.f;
+        *(bf16x8*)((tens ? bc : bm) + img_off2(row, ch)) = o;
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x101, 0xf, 0xf, true));   // row_shl:1
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x102, 0xf, 0xf, true));   // row_shl:2
+        part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x104, 0xf, 0xf, true));   // row_shl:4
+        if (ch == 0) atomicAdd(&cj[row], part);           // two adders per row (the two tensors): 16 lanes per wave-instruction
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) return;
+
+    float s[NT_MAX][4];
+    // all bias rows of the tile are requested up front, into the registers that will hold the scores
+    if constexpr (HAS_BIAS) {
 #pragma unroll
         for (int t = 0; t < NT_MAX; ++t)
             if (t < nt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - mx); s[t][r] = p; sum += p; }
+                const float4 bv = *(const float4*)(biasP + ((size_t)h * NP + q) * NP + t * 16 + 4 * g);
+                s[t][0] = bv.x; s[t][1] = bv.y; s[t][2] = bv.z; s[t][3] = bv.w;
             }
-        sum = gsum4(sum);
-        if (g == 0 && q < N) lse[(size_t)bh * N + q] = mx + __builtin_amdgcn_logf(sum);
-        const float f = inv_keep / sum;        // PD = p * f (kept) ; PD^2 = p^2 * f^2
-        f32x4 om[4], oc[4];
+    }
+    float mx = NEG_BIG;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[dt] = om[dt]; }
-        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+    for (int t = 0; t < NT_MAX; ++t) {
+        if (t < nt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
-            if (ks < nt2) {
-                const int t0 = 2 * ks, t1 = 2 * ks + 1;
-                float pa[4], pb[4], qa[4], qb[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { pa[r] = s[t0][r] * f; pb[r] = t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0][r] * f : 0.f; }
-                if (drop_thr) {
-                    bool k4[4];
-                    keep4b(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pa[r] = k4[r] ? pa[r] : 0.f;
-                    keep4b(drop_key, rowpair, t1 * 16 + 4 * g, drop_thr, k4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pb[r] = k4[r] ? pb[r] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { qa[r] = pa[r] * pa[r]; qb[r] = pb[r] * pb[r]; }
-                const bf16x8 pf = pk8(pa, pb), pf2 = pk8(qa, qb);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(vimg, t0 * 16, t1 * 16, dt * 16, lane), pf, om[dt], 0, 0, 0);
-                    oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(cvimg, t0 * 16, t1 * 16, dt * 16, lane), pf2, oc[dt], 0, 0, 0);
-                }
+            for (int kk = 0; kk < 2; ++kk) {
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bm, t * 16 + li, kk * 4 + g), A.m[kk], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowf(bc, t * 16 + li, kk * 4 + g), A.c[kk], a, 0, 0, 0);
             }
+            const float4 cv4 = *(const float4*)(cj + t * 16 + 4 * g);
+            const float cc[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float bb;
+                if constexpr (HAS_BIAS) bb = s[t][r]; else bb = (t * 16 + 4 * g + r) < N ? 0.f : NEG_BIG;
+                const float v = sigm(2.0f * a[r] - ri - cc[r]) * LOG2E + bb;     // sigmoid(-W) + bias, log2 units
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = 0.f;
         }
-        if (q < N) {
-            bf16* dm = out_m + ((size_t)b * N + q) * C + h * HD + 4 * g;
-            bf16* dc = out_c + ((size_t)b * N + q) * C + h * HD + 4 * g;
+    }
+    mx = gmax4(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t)
+        if (t < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float p = __builtin_amdgcn_exp2f(s[t][r] - mx); s[t][r] = p; sum += p; }
+        }
+    sum = gsum4(sum);
+    if (g == 0 && q < N) lse[(size_t)bh * N + q] = mx + __builtin_amdgcn_logf(sum);
+    const float f = inv_keep / sum;        // PD = p * f (kept) ; PD^2 = p^2 * f^2
+    f32x4 om[4], oc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; oc[dt] = om[dt]; }
+    const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+#pragma unroll
+    for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
+        if (ks < nt2) {
+            const int t0 = 2 * ks, t1 = 2 * ks + 1;
+            float pa[4], pb[4], qa[4], qb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pa[r] = s[t0][r] * f; pb[r] = t1 < NT_MAX ? s[t1 < NT_MAX ? t1 : 0][r] * f : 0.f; }
+            if (drop_thr) {
+                bool k4[4];
+                keep4b(drop_key, rowpair, t0 * 16 + 4 * g, drop_thr, k4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pa[r] = k4[r] ? pa[r] : 0.f;
+                keep4b(drop_key, rowpair, t1 * 16 + 4 * g, drop_thr, k4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pb[r] = k4[r] ? pb[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { qa[r] = pa[r] * pa[r]; qb[r] = pb[r] * pb[r]; }
+            const bf16x8 pf = pk8(pa, pb), pf2 = pk8(qa, qb);
+            const int r1 = t1 < nt ? t1 * 16 : t0 * 16;          // no second tile: its p is 0 (bias -1e30 / zeroed s), re-read the first
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                *(bf16x4*)(dm + dt * 16) = bf16x4{f2bf(om[dt][0]), f2bf(om[dt][1]), f2bf(om[dt][2]), f2bf(om[dt][3])};
-                *(bf16x4*)(dc + dt * 16) = bf16x4{f2bf(oc[dt][0]), f2bf(oc[dt][1]), f2bf(oc[dt][2]), f2bf(oc[dt][3])};
+                om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(vimg, t0 * 16, r1, dt * 16, lane), pf, om[dt], 0, 0, 0);
+                oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(colf(cvimg, t0 * 16, r1, dt * 16, lane), pf2, oc[dt], 0, 0, 0);
             }
+        }
+    }
+    if (q < N) {
+        bf16* dm = out_m + ((size_t)b * N + q) * C + h * HD + 4 * g;
+        bf16* dc = out_c + ((size_t)b * N + q) * C + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *(bf16x4*)(dm + dt * 16) = bf16x4{f2bf(om[dt][0]), f2bf(om[dt][1]), f2bf(om[dt][2]), f2bf(om[dt][3])};
+            *(bf16x4*)(dc + dt * 16) = bf16x4{f2bf(oc[dt][0]), f2bf(oc[dt][1]), f2bf(oc[dt][2]), f2bf(oc[dt][3])};
         }
     }
 }
@@ -330,27 +353,6 @@ __device__ __forceinline__ s16x4 col_frag16(const char* img, int col0, int lane)
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, img + img_off2(4 * g + q, (col0 >> 3) + (p >> 1)) + ((p & 1) << 3)));
 }
-__device__ __forceinline__ void dma_rows8_2(char* img, int rb, const bf16* src, size_t stride, int row0, int n_valid, int lane) {
-    const int row = row0 + 8 * rb + (lane >> 3);
-    const int chunk = (lane & 7) ^ (lane >> 3);
-    const int r = row < n_valid ? row : n_valid - 1;
-    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (size_t)r * stride + chunk * 8), LDS_PTR(void, img + rb * 1024), 16, 0, 0);
-}
-// one 16-B chunk of a token row through the transform: returns the transformed chunk and this chunk's part of the row term
-template <int TR>
-__device__ __forceinline__ bf16x8 tr_chunk(const bf16x8 v, float pre_scale, float& part) {
-    bf16x8 o;
-    part = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float x = bf2f(v[j]);
-        if constexpr (TR == TR_SIG) { x = sigm(x * pre_scale); part += x * x; }
-        else { x = sigm(x); part += x; x = sqrtf(x); }
-        o[j] = f2bf(x);
-    }
-    return o;
-}
-
 template <bool HAS_BIAS, int NT_C>
 __global__ __launch_bounds__(F2_WAVES * 64)
 void attn2_bwd_fused_kernel(const bf16* __restrict__ qkv_m, const bf16* __restrict__ qkv_c, const bf16* __restrict__ o_m,
@@ -751,11 +753,11 @@ void attn2_dbias_reduce_kernel(const uint2* __restrict__ ds, float* __restrict__
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-#define FWD2_LDS (4 * IMG_BYTES + ROWS_PAD * 4)
 static std::once_flag g_attr2_once;
 static void init2_impl() {
 #define SETA(K, B) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, B)
-    SETA(attn2_fwd_kernel<true>, FWD2_LDS); SETA(attn2_fwd_kernel<false>, FWD2_LDS);
+    SETA((attn2_fwd_kernel<true, 0>), FW2_LDS); SETA((attn2_fwd_kernel<false, 0>), FW2_LDS);
+    SETA((attn2_fwd_kernel<true, NT_MAX>), FW2_LDS); SETA((attn2_fwd_kernel<false, NT_MAX>), FW2_LDS);
     SETA((attn2_bwd_fused_kernel<true, 0>), F2_LDS); SETA((attn2_bwd_fused_kernel<false, 0>), F2_LDS);
     SETA((attn2_bwd_fused_kernel<true, NT_MAX>), F2_LDS); SETA((attn2_bwd_fused_kernel<false, NT_MAX>), F2_LDS);
 #undef SETA
@@ -765,12 +767,17 @@ static void init2() { std::call_once(g_attr2_once, init2_impl); }
 int uvit_attn2_fwd_launch(const void* qkv_m, const void* qkv_c, const float* biasP, void* out_m, void* out_c, float* lse,
                           int B, int H, int N, int NP, float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
     if (B <= 0 || H <= 0 || N <= 0 || N > NT_MAX * 16) return UVIT_ERR_SHAPE;
+    if (NP < NT_MAX * 16 || (NP & 3)) return UVIT_ERR_ARG;
     init2();
     const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-#define FA dim3(B * H), dim3(W2_WAVES * 64), FWD2_LDS, s, (const bf16*)qkv_m, (const bf16*)qkv_c, biasP, (bf16*)out_m, (bf16*)out_c, lse, \
+#define FA dim3(B * H), dim3(FW2_WAVES * 64), FW2_LDS, s, (const bf16*)qkv_m, (const bf16*)qkv_c, biasP, (bf16*)out_m, (bf16*)out_c, lse, \
         H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer)
-    if (biasP) hipLaunchKernelGGL(attn2_fwd_kernel<true>, FA); else hipLaunchKernelGGL(attn2_fwd_kernel<false>, FA);
+    if ((N + 15) / 16 == NT_MAX) {
+        if (biasP) hipLaunchKernelGGL((attn2_fwd_kernel<true, NT_MAX>), FA); else hipLaunchKernelGGL((attn2_fwd_kernel<false, NT_MAX>), FA);
+    } else {
+        if (biasP) hipLaunchKernelGGL((attn2_fwd_kernel<true, 0>), FA); else hipLaunchKernelGGL((attn2_fwd_kernel<false, 0>), FA);
+    }
 #undef FA
     return uvit_check_launch();
 }
