@@ -1219,41 +1219,6 @@ void gemm_tn256_group_kernel(const TnGroup G) {
     // problem, so the Y panels of a tile row and the X panels of a tile column are fetched into that L2 once
     // (without it the launch moves 3.7x its operand bytes through the fabric and is bandwidth-bound: profiles/)
     int b = xcd_remap(blockIdx.x, gridDim.x), c = 0, p = 0;
-    // tile order inside a problem: walk the SHORTER tile dimension fastest, so that a contiguous item range (one XCD's share) touches few
-    // panels of the longer one -- fc2 (3 x 12 tiles): 27 consecutive items then read 3 Y + 9 X panels instead of 3 + 12
-    auto tile_of = [&](const TnProb& P, int idx, int& tn, int& tk) {
-        if (P.tiles_k > P.tiles_n) { tk = idx / P.tiles_n; tn = idx - tk * P.tiles_n; }
-        else { tn = idx / P.tiles_k; tk = idx - tn * P.tiles_k; }
-    };
-    auto bias_of = [&](const TnProb& P, int tn, int tk) -> float* {
-        if (tk != 0 || !P.bias) return nullptr;
-        const int n0 = tn * T_BM;                      // bias segments are multiples of 256 columns
-        if (n0 < P.bias_end) return P.bias + n0;
-        if (P.bias2 && n0 >= P.bias2_begin) return P.bias2 + (n0 - P.bias2_begin);
-        return nullptr;
-    };
-    if (G.bal_main > 0 && b >= G.bal_main) {
-        // balanced plan, tail workgroup: the last K-tiles [bal_t0, nm) of bal_k consecutive tiles, one segment after the other
-        const int first = (b - G.bal_main) * G.bal_k;
-        for (int k = 0; k < G.bal_k; ++k) {
-            int idx = first + k;
-            if (idx >= G.bal_tiles) break;
-            int q = 0;
-            for (; q < G.nprob; ++q) {
-                const int nt = G.p[q].tiles_n * G.p[q].tiles_k;
-                if (idx < nt) break;
-                idx -= nt;
-            }
-            const TnProb& P = G.p[q];
-            int tn, tk;
-            tile_of(P, idx, tn, tk);
-            const int nk = P.nm - G.bal_t0;
-            if (nk > 0)
-                tn256_segment(smem, (const bf16*)P.Y, (const bf16*)P.X, P.ldy, P.ldx, tn * T_BM, tk * T_BN, G.bal_t0, nk, P.C, P.ldc, true, lane,
-                              wave, bias_of(P, tn, tk), true);
-        }
-        return;
-    }
     bool found = false;
     for (c = 0; c < G.max_chunks && !found; ++c)
         for (p = 0; p < G.nprob; ++p) {
@@ -1265,13 +1230,22 @@ void gemm_tn256_group_kernel(const TnGroup G) {
     if (!found) return;
     c -= 1;                                            // the for statement stepped once more after the hit
     const TnProb& P = G.p[p];
+    // tile order inside a problem: walk the SHORTER tile dimension fastest, so that a contiguous item range (one XCD's share) touches few
+    // panels of the longer one -- fc2 (3 x 12 tiles): 27 consecutive items then read 3 Y + 9 X panels instead of 3 + 12
     int tn, tk;
-    tile_of(P, b, tn, tk);
+    if (P.tiles_k > P.tiles_n) { tk = b / P.tiles_n; tn = b - tk * P.tiles_n; }
+    else { tn = b / P.tiles_k; tk = b - tn * P.tiles_k; }
     const int t0 = c * P.chunk_steps;
-    const int nk = min(P.chunk_steps, (G.bal_main > 0 ? G.bal_t0 : P.nm) - t0);
+    const int nk = min(P.chunk_steps, P.nm - t0);
     if (nk <= 0) return;
+    float* bias = nullptr;
+    if (tk == 0 && P.bias) {
+        const int n0 = tn * T_BM;                      // bias segments are multiples of 256 columns
+        if (n0 < P.bias_end) bias = P.bias + n0;
+        else if (P.bias2 && n0 >= P.bias2_begin) bias = P.bias2 + (n0 - P.bias2_begin);
+    }
     tn256_segment(smem, (const bf16*)P.Y, (const bf16*)P.X, P.ldy, P.ldx, tn * T_BM, tk * T_BN, t0, nk, P.C, P.ldc,
-                  P.chunks > 1 || G.bal_main > 0, lane, wave, bias_of(P, tn, tk), true);
+                  P.chunks > 1, lane, wave, bias, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1281,13 +1255,11 @@ void gemm_tn256_group_kernel(const TnGroup G) {
 // The only process-wide data are write-once caches of device facts (CU count, LDS opt-in), set under std::call_once.
 static std::once_flag g_init_flag;
 static int g_num_cu = 256;
-static int g_tn_balance_env = -1;    // UVIT_TN_BALANCE=0 switches the balanced wgrad plan off (A/B runs), read once
 static const GemmTune g_default_tune;
 template <typename F>
 static void allow_lds(F f) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_BYTES); }
 
 static void gemm_init_impl() {
-    { const char* e_ = getenv("UVIT_TN_BALANCE"); if (e_) g_tn_balance_env = atoi(e_); }
     allow_lds(gemm_nt_kernel<EPI_BF16>); allow_lds(gemm_nt_kernel<EPI_QKV>); allow_lds(gemm_nt_kernel<EPI_GELU>);
     allow_lds(gemm_nt_kernel<EPI_RESID>); allow_lds(gemm_nt_kernel<EPI_F32>); allow_lds(gemm_nt_kernel<EPI_PATCH>);
     allow_lds(gemm_nt_kernel<EPI_DGELU>); allow_lds(gemm_nt_kernel<EPI_QKV_ELU>);
@@ -1525,28 +1497,6 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const G
         G.p[i].chunks = (G.p[i].nm + L - 1) / L;
         G.max_chunks = G.max_chunks > G.p[i].chunks ? G.max_chunks : G.p[i].chunks;
     }
-    // Balanced plan (round 4): when the items of the best plan leave CUs idle in their ONE round (ViT-B layer: 108 tiles x 2 chunks = 216
-    // items on 256 CUs), shorten the main pieces to f K-tiles and give the rest of every tile, [chunks x f, nm), to the idle CUs, bal_k
-    // tails each, so that a tail workgroup's bal_k short segments take as long as one main piece: f + o = bal_k (nm - chunks f + o), o = the
-    // fixed cost of a segment (prologue + atomic epilogue) in K-tile units.  Every problem must reduce over the same token count.
-    int grid = items;
-    const int bal_env = (tune ? tune : &g_default_tune)->tn_balance && g_tn_balance_env != 0;
-    if (bal_env && items < g_num_cu && items * 8 >= g_num_cu * 5) {
-        bool same = true; int tiles = 0;
-        for (int i = 0; i < n; ++i) { same = same && G.p[i].nm == nm_max && G.p[i].chunks == G.p[0].chunks; tiles += G.p[i].tiles_n * G.p[i].tiles_k; }
-        const int sp = G.p[0].chunks, extra = g_num_cu - items;
-        if (same && tiles * sp == items && extra > 0) {
-            const int k = (tiles + extra - 1) / extra;
-            const double ovh = 12.0;
-            int f = (int)((k * (double)nm_max + (k - 1) * ovh) / (1.0 + (double)k * sp) + 0.999);
-            const int tail = nm_max - sp * f;
-            if (f >= 8 && tail >= 8 && k <= 8) {
-                for (int i = 0; i < n; ++i) G.p[i].chunk_steps = f;
-                G.bal_main = items; G.bal_t0 = sp * f; G.bal_k = k; G.bal_tiles = tiles;
-                grid = items + (tiles + k - 1) / k;
-            }
-        }
-    }
-    hipLaunchKernelGGL(gemm_tn256_group_kernel, dim3(grid), dim3(T_THREADS), T_LDS_BYTES, s, G);
+    hipLaunchKernelGGL(gemm_tn256_group_kernel, dim3(items), dim3(T_THREADS), T_LDS_BYTES, s, G);
     return uvit_check_launch();
 }

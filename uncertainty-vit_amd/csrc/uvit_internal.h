@@ -38,7 +38,6 @@ struct GemmTune {
     int tn_variant = 3;      // 0: 128x128 kernel, 1: 256x256 staggered kernel, 3: auto
     int tn_target = 512;     // workgroups the wgrad split-K aims for (MI355X sweep: 512 beats 256..1536 on all four wgrad shapes)
     int group_chunks = 0;    // grouped wgrad: 0 = cost model, > 0 = forced token-chunk count
-    int tn_balance = 1;      // grouped wgrad: tails of every tile on the CUs the one-round plan leaves idle (0 = off)
     int nt_group = 0;        // 256x256 NT kernel: column tiles per row-tile group of the tile order (0 = default 6)
     int nt_persist = 1;      // 256x256 NT kernel, more tiles than CUs: persistent workgroups, operand pipeline across tiles
 };
@@ -62,12 +61,7 @@ struct TnProb {
     // filled by the launcher
     int nm = 0, tiles_n = 0, tiles_k = 0, chunk_steps = 0, chunks = 0;
 };
-struct TnGroup {
-    TnProb p[UVIT_TN_GROUP_MAX]; int nprob = 0; int max_chunks = 0;
-    // balanced plan (round 4; 0 = off): the first bal_main workgroups run the main pieces (chunks x chunk_steps tokens of every tile, which
-    // now stop at K-tile bal_t0), every later workgroup runs the tails [bal_t0, nm) of bal_k consecutive tiles
-    int bal_main = 0, bal_t0 = 0, bal_k = 0, bal_tiles = 0;
-};
+struct TnGroup { TnProb p[UVIT_TN_GROUP_MAX]; int nprob = 0; int max_chunks = 0; };
 bool uvit_gemm_tn_group_ok(const TnProb* probs, int n, const GemmTune* tune = nullptr);
 int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const GemmTune* tune = nullptr);
 
