@@ -336,7 +336,7 @@ def main():
         check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
     # the step without the masked-row bound (every row through the last block's MLP): img/s beside `value`, same run
     all_rows_value = None
-    if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone:
+    if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)
         keep = feed["mask_rows"]
         feed["mask_rows"] = 0
         for i in range(2):

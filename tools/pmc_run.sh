@@ -12,10 +12,11 @@ cd /tmp
 # optional third / fourth pass (PMC_EXTRA="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum", when `rocprofv3 -L` lists them): the requests that
 # reach HBM itself -- FETCH_SIZE / WRITE_SIZE count the L2's fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM)
 for c in FETCH_SIZE WRITE_SIZE $PMC_EXTRA; do
-  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-input-staging --single-stream --model $model > $out/$c.log 2>&1 || { echo "pmc pass $c failed"; tail -5 $out/$c.log; exit 1; }
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/$c -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-input-staging --single-stream --all-rows --model $model > $out/$c.log 2>&1 || { echo "pmc pass $c failed"; tail -5 $out/$c.log; exit 1; }
 done
 cd $root
-# one instantiation, two shapes in a fixed rotation (single-stream run): proj, fc2, proj, fc2, ...
+# one instantiation, two shapes in a fixed rotation: proj, fc2, proj, fc2, ... (single-stream --all-rows run: with the masked-row bound the
+# last block's fc2 is another kernel and the rotation would flip after every forward)
 for c in FETCH_SIZE WRITE_SIZE $PMC_EXTRA; do
   python tools/pmc_summary.py $out/$c "gemm_nt256_kernel<3, 5" --alternate 2 proj,fc2 | sed "s/^.*counter_collection.csv: /$c: /"
 done | tee $out/summary_resid.txt

@@ -809,7 +809,10 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
             pj.M = Mred1; pj.Nn = C; pj.Kk = C; pj.ldy = C; pj.ldx = C; pj.ldc = C;
         }
         TnProb& qk = wg[nwg++]; qk.Y = dqkv; qk.X = a.ln1; qk.C = g + o.qkvw; qk.M = Mred; qk.Nn = 3 * C; qk.Kk = C; qk.ldy = 3 * C; qk.ldx = C; qk.ldc = C;
-        if (S == 1) { qk.bias = RP(off_qb(o, 0)); qk.bias_end = C; qk.bias2 = RP(off_vb(o, 0)); qk.bias2_begin = 2 * C; }
+        qk.bias = RP(off_qb(o, 0)); qk.bias_end = C; qk.bias2 = RP(off_vb(o, 0)); qk.bias2_begin = 2 * C;
+        // two-stream: the q / v biases differ per stream while the stacked wgrad reduces over both: the token chunks of stream 1
+        // (rows from Mpad on) sum into the covariance stream's biases (round 4; was 4 colsum launches per layer)
+        if (S == 2) { qk.bias_s1 = RP(off_qb(o, 1)); qk.bias2_s1 = RP(off_vb(o, 1)); qk.s1_row = (int)Mp; }
     }
     const bool grouped = uvit_gemm_tn_group_ok(wg, nwg, &e->tune);
     // --- MLP branch: x_out = x_mid + dp * gamma2 * fc2(gelu(fc1(ln2(x_mid))))   (weights shared by the streams)
@@ -881,7 +884,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     e->slab_started = true;
     CHECK(handoff(3));
-    if (!grouped || S > 1)        // two-stream: the q / v biases differ per stream while the stacked wgrad sums both
+    if (!grouped)
         for (int st = 0; st < S; ++st) {
             CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
             CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));

@@ -1241,8 +1241,12 @@ void gemm_tn256_group_kernel(const TnGroup G) {
     float* bias = nullptr;
     if (tk == 0 && P.bias) {
         const int n0 = tn * T_BM;                      // bias segments are multiples of 256 columns
-        if (n0 < P.bias_end) bias = P.bias + n0;
-        else if (P.bias2 && n0 >= P.bias2_begin) bias = P.bias2 + (n0 - P.bias2_begin);
+        // stacked two-stream rows: a chunk lies in one stream (the launcher only plans such chunk lengths) and sums into that stream's bias
+        const bool s1 = P.s1_row > 0 && t0 * BK >= P.s1_row;
+        float* b1 = s1 ? P.bias_s1 : P.bias;
+        float* b2 = s1 ? P.bias2_s1 : P.bias2;
+        if (n0 < P.bias_end) bias = b1 + n0;
+        else if (b2 && n0 >= P.bias2_begin) bias = b2 + (n0 - P.bias2_begin);
     }
     tn256_segment(smem, (const bf16*)P.Y, (const bf16*)P.X, P.ldy, P.ldx, tn * T_BM, tk * T_BN, t0, nk, P.C, P.ldc,
                   P.chunks > 1, lane, wave, bias, true);
@@ -1450,6 +1454,9 @@ bool uvit_gemm_tn_group_ok(const TnProb* probs, int n, const GemmTune* tune) {
         const TnProb& q = probs[i];
         if (q.M <= 0 || (q.M % BK) || q.M / BK < 8 || (q.Nn % T_BM) || (q.Kk % T_BN) || (q.ldy % 8) || (q.ldx % 8) || (q.ldc % 4)) return false;
         if (q.bias && ((q.bias_end % T_BM) || (q.bias2 && (q.bias2_begin % T_BM)))) return false;
+        // (the planner needs a 2-chunk plan to exist: at least 16 K-tiles, the boundary at or just above half of them)
+        if (q.s1_row && (!q.bias || !q.bias_s1 || (q.bias2 && !q.bias2_s1) || (q.s1_row % BK) || q.s1_row >= q.M || q.M / BK < 16 ||
+                         (q.M / BK + 1) / 2 != q.s1_row / BK)) return false;
     }
     return true;
 }
@@ -1479,8 +1486,13 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const G
     };
     int best_sp = 1; double best_cost = 1e30;
     const int sp_max = nm_max / 8 < 16 ? nm_max / 8 : 16;
+    auto stream_ok = [&](int L) {                     // no chunk [c L, (c + 1) L) of a two-stream problem straddles its stream boundary
+        for (int i = 0; i < n; ++i) if (probs[i].s1_row && ((probs[i].s1_row / BK) % L)) return false;
+        return true;
+    };
     for (int sp = 1; sp <= (sp_max < 1 ? 1 : sp_max); ++sp) {
         int items; const int L = plan(sp, items);
+        if (!stream_ok(L)) continue;
         double atomic_bytes = 0.0;
         for (int i = 0; i < n; ++i) {
             const int ch = (G.p[i].nm + L - 1) / L;
@@ -1491,6 +1503,7 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const G
     }
     if (group_chunks > 0) best_sp = group_chunks < (nm_max / 4 > 1 ? nm_max / 4 : 1) ? group_chunks : (nm_max / 4 > 1 ? nm_max / 4 : 1);
     int items; const int L = plan(best_sp, items);
+    if (!stream_ok(L)) return UVIT_ERR_SHAPE;          // (sp = 2 always qualifies when the boundary is half the rows: the engine's stacked layout)
     G.max_chunks = 0;
     for (int i = 0; i < n; ++i) {
         G.p[i].chunk_steps = L;

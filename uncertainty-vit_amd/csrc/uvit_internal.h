@@ -57,6 +57,9 @@ struct TnProb {
     float* bias = nullptr;           // column sums of Y[:, 0:bias_end) (null: none)
     float* bias2 = nullptr;          // column sums of Y[:, bias2_begin:Nn) (qkv: v_bias; null: none)
     int bias_end = 0, bias2_begin = 0;
+    // stacked two-stream operands (rows [0, s1_row) = mean stream, [s1_row, M) = covariance stream) whose bias differs per stream: the
+    // column sums of the rows from s1_row on go to bias_s1 / bias2_s1 (s1_row = 0: one stream); every token chunk must lie in ONE stream
+    float* bias_s1 = nullptr; float* bias2_s1 = nullptr; int s1_row = 0;
     int M = 0, Nn = 0, Kk = 0, ldy = 0, ldx = 0, ldc = 0;
     // filled by the launcher
     int nm = 0, tiles_n = 0, tiles_k = 0, chunk_steps = 0, chunks = 0;
