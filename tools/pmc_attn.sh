@@ -20,7 +20,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$out/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for tag in ("attn_bwd_fused2", "attn_bwd_fused_kernel", "attn_fwd", "attn_dbias"):
+        for tag in ("attn2_bwd_fused", "attn2_fwd", "attn2_dbias", "attn_bwd_fused_kernel", "attn_fwd_kernel", "attn_dbias"):
             if tag in k:
                 acc[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for tag, d in acc.items():
