@@ -45,6 +45,7 @@ def shapes(two_stream=False):
     k["attn_dbias_reduce_kernel"] = (0.0, bf * B * H * 208 * 224 + f4 * H * 208 * 208)
     k["void attn2_fwd_kernel"] = (2 * att, bf * (2 * M * 3 * C + 2 * M * C) + f4 * H * 208 * 208)
     k["void attn2_bwd_fused_kernel"] = (5 * att, bf * (2 * M * 3 * C * 2 + 4 * M * C) + bf * B * H * 208 * 208)
+    k["_Z22attn2_bwd_fused_kernel"] = k["void attn2_bwd_fused_kernel"]            # (rocprofv3 prints some names mangled)
     k["attn2_dbias_reduce_kernel"] = (0.0, bf * B * H * 208 * 208 + f4 * H * 208 * 208)
     k["_Z13ln_fwd_kernel"] = (0.0, Ms * C * (f4 + bf))
     k["_Z13ln_bwd_kernelILi3ELb1E"] = (0.0, M * C * (bf + f4 + f4 + f4 + bf + bf))                                              # dy, x, dres -> dx; y_next -> dy_next
