@@ -37,7 +37,10 @@ def close(a, b, rtol, atol, what):
     assert bad == 0, f"{what}: {bad}/{a.numel()} off, max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
 
 
-@pytest.mark.parametrize("B,H,N", [(2, 2, 10), (2, 12, 197), (3, 2, 37)])
+@pytest.mark.parametrize("B,H,N", [(2, 2, 10), (2, 12, 197), (3, 2, 37),
+                                   # round 4 (13-wave forward, fused 16-key-step backward): every tile-count edge of the kernels -- one token, exact
+                                   # multiples of 16, one over, odd / even tile counts, the largest supported N (all 13 tiles full)
+                                   (1, 1, 1), (2, 1, 16), (1, 2, 17), (1, 1, 32), (2, 1, 33), (1, 1, 100), (1, 2, 176), (1, 1, 192), (1, 1, 193), (1, 2, 208)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_wasserstein_attention_fwd_bwd(B, H, N, p_drop):
     from uncertainty_vit_amd import native
@@ -86,7 +89,9 @@ def test_wasserstein_attention_fwd_bwd(B, H, N, p_drop):
                                P(slab), 0, P(ws), B, H, N, 208, 0.125, p_drop, seed, layer, S()) == 0
     close(dq_m, qm.grad, 5e-2, 2e-2 * qm.grad.abs().max().item(), "d qkv (mean stream)")
     close(dq_c, pc.grad, 5e-2, 2e-2 * pc.grad.abs().max().item(), "d qkv (cov stream, pre-ELU)")
-    close(slab[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item(), "d rel-pos bias")
+    # (N = 1: the exact gradient is 0 = p (dP - delta) with p = 1; the kernel's delta comes from the bf16-rounded outputs, so what is left is
+    #  the rounding of a difference of two O(|dO.O|) numbers: an absolute floor instead of a bound relative to a zero reference)
+    close(slab[:, :N, :N].transpose(1, 2), bq.grad, 5e-2, 2e-2 * bq.grad.abs().max().item() + (1e-1 if N == 1 else 0.0), "d rel-pos bias")
 
 
 def dist_model(cfg):
