@@ -358,7 +358,15 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     {
         const char* env = getenv("UVIT_SINGLE_STREAM");
         e->dual = !(env && env[0] == '1');
-        bool ok = hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess;
+        // The second stream runs BELOW the caller's stream (round 4): what it carries -- teacher forward, weight gradients, bias-gradient
+        // reductions, the transposed weight copies -- is off the critical path of the step (student forward -> loss -> dgrad chain), and
+        // the dispatcher then hands free CUs to the critical chain first: 25.41 -> 25.03 ms per step (tools/ab.sh, 4 alternating pairs;
+        // above the caller's stream: +1 %).  UVIT_AUX_PRIO = 0 restores equal priorities for A/B runs, -1 puts it above.
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* pe = getenv("UVIT_AUX_PRIO");
+        const int pv = pe ? atoi(pe) : 1;
+        const int prio = pv < 0 ? hi : pv > 0 ? lo : 0;
+        bool ok = hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) == hipSuccess;
         auto mk = [&](hipEvent_t* ev) { ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
         mk(&e->ev_fork); mk(&e->ev_teacher); mk(&e->ev_ds);
         for (int i = 0; i < 4; ++i) mk(&e->ev_x[i]);
@@ -953,6 +961,7 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
                             hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
                             e->gnorm, s, e->loss, (hp->do_ema || hp->sched_dev) ? e->buf.ema : nullptr, e->buf.ema_bf16, hp->ema_decay, e->poisoned,
                             hp->sched_dev, hp->sched_len, hp->sched_index));
+    // (round 4 tried these transposed copies on the second stream, beside the next forward: 24.9-25.2 vs 24.7-25.2 ms per step, no gain)
     CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
     // frozen tensors (two-stream cov_qkv.weight) sit behind n_live: AdamW never touches them, the reference's EMA does
     // average them (ModelEmaV2 walks every state-dict value) -- a no-op on values that never change, skipped
