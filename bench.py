@@ -333,7 +333,7 @@ def main():
         fence()
         check(L.uvit_engine_profile(engine.h, 0, 0), "profile off")
         alone = read_kinds()
-        check(L.uvit_engine_set_streams(engine.h, 1), "set_streams")
+        check(L.uvit_engine_set_streams(engine.h, engine.stream_mode), "set_streams")
     # the step without the masked-row bound (every row through the last block's MLP): img/s beside `value`, same run
     all_rows_value = None
     if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)

@@ -174,8 +174,10 @@ void uvit_tuning_default(uvit_tuning* out);
 /* Replace the engine's tuning (values outside the lists above are refused with UVIT_ERR_ARG). */
 int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t);
 /* dual = 1 (default): teacher forward and the wgrad GEMMs run on an internal second HIP stream beside the
- * caller's stream; dual = 0: everything on the caller's stream (used to time one kernel in isolation).
- * Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
+ * caller's stream; dual = 2: the same on a second stream of LOWER priority than the caller's (the critical chain of the
+ * step gets free CUs first: faster with the whole GPU to itself, slower when other kernels -- RCCL -- hold CUs, so the
+ * host mirror selects it for single-GPU runs only); dual = 0: everything on the caller's stream (used to time one
+ * kernel in isolation).  Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
 int uvit_engine_set_streams(uvit_engine* e, int dual);
 /* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
  * fused bias+GELU, gemm_nt256_kernel<EPI_GELU / EPI_GELU_DG>) with HIP events on the stream it runs on.

@@ -169,7 +169,7 @@ struct uvit_engine {
     int compact_R = 0;      // > 0: this step runs the last block's MLP on the masked rows only, in R (multiple of 64) compact rows (uvit_step_params.n_rows_hint)
     // second stream: teacher forward beside student forward; wgrad GEMMs beside the dgrad chain
     bool dual = true;
-    hipStream_t aux = nullptr;
+    hipStream_t aux = nullptr, aux_eq = nullptr, aux_lo = nullptr;     // aux = the one in use (uvit_engine_set_streams)
     hipEvent_t ev_fork = nullptr, ev_teacher = nullptr, ev_x[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_wdone[UVIT_MAX_DEPTH] = {};
     hipEvent_t ev_ds = nullptr;             // dS of the current layer is complete (main stream -> second stream)
@@ -358,15 +358,16 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     {
         const char* env = getenv("UVIT_SINGLE_STREAM");
         e->dual = !(env && env[0] == '1');
-        // The second stream runs BELOW the caller's stream (round 4): what it carries -- teacher forward, weight gradients, bias-gradient
-        // reductions, the transposed weight copies -- is off the critical path of the step (student forward -> loss -> dgrad chain), and
-        // the dispatcher then hands free CUs to the critical chain first: 25.41 -> 25.03 ms per step (tools/ab.sh, 4 alternating pairs;
-        // above the caller's stream: +1 %).  UVIT_AUX_PRIO = 0 restores equal priorities for A/B runs, -1 puts it above.
+        // Two second streams: one at the caller's priority, one BELOW it (round 4).  What the second stream carries -- teacher forward,
+        // weight gradients, bias-gradient reductions -- is off the critical chain of the step (student forward -> loss -> dgrad chain), and
+        // with the lower priority the dispatcher hands free CUs to the critical chain first: 25.41 -> 25.03 ms per step on all 256 CUs
+        // (tools/ab.sh, 4 alternating pairs).  With CUs taken away it is the other way round (240 CUs: 28.51 -> 29.21 ms: the 216 wgrad
+        // workgroups then queue behind the chain and finish late), so the host selects it for single-GPU runs only
+        // (uvit_engine_set_streams(e, 2)); data-parallel runs, where RCCL's channel workgroups hold CUs during backward, keep mode 1.
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const char* pe = getenv("UVIT_AUX_PRIO");
-        const int pv = pe ? atoi(pe) : 1;
-        const int prio = pv < 0 ? hi : pv > 0 ? lo : 0;
-        bool ok = hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio) == hipSuccess;
+        bool ok = hipStreamCreateWithFlags(&e->aux_eq, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithPriority(&e->aux_lo, hipStreamNonBlocking, lo) == hipSuccess;
+        e->aux = e->aux_eq;
         auto mk = [&](hipEvent_t* ev) { ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess; };
         mk(&e->ev_fork); mk(&e->ev_teacher); mk(&e->ev_ds);
         for (int i = 0; i < 4; ++i) mk(&e->ev_x[i]);
@@ -380,7 +381,8 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
 extern "C" void uvit_engine_destroy(uvit_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
-    if (e->aux) { (void)hipStreamSynchronize(e->aux); (void)hipStreamDestroy(e->aux); }
+    if (e->aux_eq) { (void)hipStreamSynchronize(e->aux_eq); (void)hipStreamDestroy(e->aux_eq); }
+    if (e->aux_lo) { (void)hipStreamSynchronize(e->aux_lo); (void)hipStreamDestroy(e->aux_lo); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_teacher) (void)hipEventDestroy(e->ev_teacher);
     if (e->ev_ds) (void)hipEventDestroy(e->ev_ds);
@@ -411,7 +413,11 @@ extern "C" int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t) {
 }
 
 extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
-    if (!e) return UVIT_ERR_ARG;
+    if (!e || dual < 0 || dual > 2) return UVIT_ERR_ARG;
+    // switching streams between steps: whatever the old second stream still holds must be ordered before the new one's work
+    hipStream_t next = dual == 2 ? e->aux_lo : e->aux_eq;
+    if (next != e->aux && e->aux) HIPCHECK(hipStreamSynchronize(e->aux));
+    e->aux = next;
     e->dual = dual != 0;
     return UVIT_OK;
 }

@@ -104,6 +104,15 @@ class NativeEngine:
         if not self.h:
             check(err.value or -1, "uvit_engine_create")
         self.h = C.c_void_p(self.h)
+        # second-stream mode (include/uvit.h, uvit_engine_set_streams): below the caller's stream when this process has the GPU to itself;
+        # equal priority in data-parallel runs, where RCCL's channel workgroups hold CUs during backward
+        import os
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.stream_mode = 0 if os.environ.get("UVIT_SINGLE_STREAM") == "1" else (2 if world == 1 else 1)
+        if os.environ.get("UVIT_STREAM_MODE"):          # A/B runs
+            self.stream_mode = int(os.environ["UVIT_STREAM_MODE"])
+        check(L.uvit_engine_set_streams(self.h, self.stream_mode), "set_streams")
         self.sync_shadows(3)
 
     def sync_shadows(self, which=3):
