@@ -217,6 +217,12 @@ int uvit_op_gemm_nt(int mode, const void* A_bf16, const void* W_bf16, int M, int
  * launcher handed to its row-split tail launch (0 = single launch). */
 int uvit_op_gemm_nt_tuned(int mode, const void* A_bf16, const void* W_bf16, int M, int N, int K, int lda, int ldw,
                           const uvit_gemm_epilogue* epi, const uvit_tuning* tune, int* tail_rows, uvit_stream stream);
+/* The same with DYNAMIC tile assignment for the persistent 256x256 kernel (round 4): tile_counters = 16 uint32 in device memory, zero
+ * before the first launch (every launch leaves them zero again; launches that may run concurrently need their own 16).  The workgroups
+ * then take tiles from per-XCD counters instead of by a fixed stride, so a launch that finds CUs occupied by other work (RCCL's channel
+ * workgroups in a data-parallel run) takes tiles / free CUs longer instead of twice as long.  NULL = fixed stride. */
+int uvit_op_gemm_nt_sched(int mode, const void* A_bf16, const void* W_bf16, int M, int N, int K, int lda, int ldw,
+                          const uvit_gemm_epilogue* epi, const uvit_tuning* tune, uint32_t* tile_counters, uvit_stream stream);
 /* C[N,K] (f32) = Y[M,N]^T . X[M,K]: weight gradients; M must be a multiple of 64.  tune: NULL = defaults */
 int uvit_op_gemm_tn(const void* Y_bf16, const void* X_bf16, int M, int N, int K, int ldy, int ldx, float* C, int ldc,
                     const uvit_tuning* tune, uvit_stream stream);

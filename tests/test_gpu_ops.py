@@ -170,6 +170,32 @@ def test_gemm_nt_persistent_workgroups(L):
         close(outs[0], ref, rtol=2e-3, atol=2e-3, what=f"persistent {M}x{N}x{K}")
 
 
+def test_gemm_nt_persistent_dynamic_tile_assignment(L):
+    """uvit_op_gemm_nt_sched: the persistent workgroups take their tiles from per-XCD counters instead of by a fixed stride (round 4).
+    Bit-identical to the fixed-stride launch (a tile's arithmetic does not depend on who computes it), also when another kernel keeps part
+    of the GPU busy so that workgroups start late and the shares differ from launch to launch; the counters are back at zero every time."""
+    from uncertainty_vit_amd.native import Tuning
+    cnt = torch.zeros(16, dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    junk = torch.randn(8192, 8192, device="cuda")
+    for M, N, K in [(25216, 3072, 192), (25216, 2304, 768), (9000, 768, 320), (300, 256, 128)]:
+        a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=0.05, seed=2)), rnd(N, seed=3)
+        out32 = torch.zeros(M, N, device="cuda")
+        with tuned(nt_variant=1, nt_persist=1) as tu:
+            ok(nt(L, 4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), S()))
+            ref = out32.clone()
+            for rep in range(8):
+                if rep % 2:
+                    with torch.cuda.stream(side):
+                        junk = (junk @ junk) * 1e-4          # a long kernel that holds CUs while the persistent workgroups are dispatched
+                out32.zero_()
+                ok(L.uvit_op_gemm_nt_sched(4, P(a), P(w), M, N, K, K, K, C.byref(epi(out=out32, bias=b, ldo=N)), C.byref(tu), P(cnt), S()))
+                torch.cuda.synchronize()
+                assert torch.equal(out32, ref), (M, N, K, rep)
+                assert int(cnt.abs().sum()) == 0, "the tile counters were not put back to zero"
+        close(ref, a.float() @ w.float().t() + b, rtol=2e-3, atol=2e-3, what=f"dynamic {M}x{N}x{K}")
+
+
 def test_gemm_nt_row_split_of_a_nearly_empty_last_round(L):
     """Auto dispatch sends the row tiles that overflow whole rounds of 256x256 tiles (fc2: 297 tiles on 256 CUs) to the
     128x128 kernel: the residual epilogue's per-sample drop-path scale must keep indexing by the global row."""

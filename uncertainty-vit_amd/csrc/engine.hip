@@ -161,6 +161,7 @@ struct uvit_engine {
     int* poisoned;         // sticky: set by the first step whose loss / gradient norm is not finite; AdamW and EMA then skip every step
     TransposeDesc* tdesc; int n_tdesc, n_ttiles;
     int64_t* mask_copy;
+    unsigned* tile_cnt = nullptr;   // 2 x 16 counters (caller's stream, second stream): dynamic tile assignment of the persistent GEMMs
     float* grep;           // [NREP][no-decay region] replicated column-sum accumulators
     size_t n_nd;           // floats in the live (not frozen) part of the no-decay region
     bool slab_started;
@@ -240,6 +241,7 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     e->tdesc = b.take<TransposeDesc>(7 * c.depth + 4);
     e->mask_copy = b.take<int64_t>(e->BP + 64);
     e->grep = b.take<float>((size_t)NREP * e->n_nd);
+    e->tile_cnt = b.take<unsigned>(64);          // zero from the workspace memset; every launch leaves its counters at zero
 }
 
 static void fill_dims(uvit_engine* e) {
@@ -509,9 +511,13 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     const int M = Bc * e->N, C = e->C, Hd = e->Hd, S = e->S;
     const size_t Mp = e->Mpad;                                   // row offset of stream 1
     const int Mall = (int)((size_t)(S - 1) * Mp + M);
+    // counters of the persistent GEMMs' dynamic tile assignment: one block per stream (the teacher and student forwards run side by side)
+    static const bool dyn_tiles = !(getenv("UVIT_DYN_TILES") && getenv("UVIT_DYN_TILES")[0] == '0');     // A/B switch
+    unsigned* const tcnt = (e->tile_cnt && dyn_tiles) ? e->tile_cnt + ((e->dual && s == e->aux) ? 16 : 0) : nullptr;
     CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, Mall, C, e->cfg.ln_eps, s));
     for (int st = 0; st < S; ++st) {     // same qkv.weight for both streams (modeling_finetune_dist.py:121,127)
         GemmEpi q; q.out = a.qkv + st * Mp * 3 * C; q.bias = w.f + off_qb(o, st); q.bias2 = w.f + off_vb(o, st); q.ldo = 3 * C;
+        q.tile_counter = tcnt;
         CHECK(GEMM_NT(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
     }
     if (S == 1) {
@@ -537,7 +543,7 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     }
     if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
     else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
-    GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd;
+    GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd; f1.tile_counter = tcnt;
     const bool prof = R == 0 && prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T);    // (only full-size launches are timed)
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
     CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, R > 0 ? R : Mall, Hd, C, C, C, &f1, s));
@@ -1000,21 +1006,35 @@ extern "C" int uvit_engine_read_stats(uvit_engine* e, float* host_out2, uvit_str
 // operator-level C ABI (thin wrappers over the internal launchers)
 // ------------------------------------------------------------------------------------------
 #define S(x) ((hipStream_t)(x))
+static GemmEpi epi_from_abi(const uvit_gemm_epilogue* ep) {
+    GemmEpi g; g.out = ep->out; g.out2 = ep->out2; g.bias = ep->bias; g.bias2 = ep->bias2; g.gamma = ep->gamma;
+    g.resid = ep->resid; g.rowscale = ep->rowscale; g.aux = ep->aux; g.mask = ep->mask; g.mask_token = ep->mask_token;
+    g.ldo = ep->ldo; g.tokens = ep->tokens > 0 ? ep->tokens : 1; g.patches = ep->patches > 0 ? ep->patches : 1;
+    g.row0 = ep->row0;
+    return g;
+}
 extern "C" int uvit_op_gemm_nt_tuned(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
                                      const uvit_gemm_epilogue* ep, const uvit_tuning* tune, int* tail_rows, uvit_stream st) {
     if (!A || !W || !ep || !ep->out) return UVIT_ERR_ARG;
     GemmTune tu;
     const int trc = tune_from_abi(tune, tu);
     if (trc) return trc;
-    GemmEpi g; g.out = ep->out; g.out2 = ep->out2; g.bias = ep->bias; g.bias2 = ep->bias2; g.gamma = ep->gamma;
-    g.resid = ep->resid; g.rowscale = ep->rowscale; g.aux = ep->aux; g.mask = ep->mask; g.mask_token = ep->mask_token;
-    g.ldo = ep->ldo; g.tokens = ep->tokens > 0 ? ep->tokens : 1; g.patches = ep->patches > 0 ? ep->patches : 1;
-    g.row0 = ep->row0;
+    GemmEpi g = epi_from_abi(ep);
     return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st), &tu, tail_rows);
 }
 extern "C" int uvit_op_gemm_nt(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
                                const uvit_gemm_epilogue* ep, uvit_stream st) {
     return uvit_op_gemm_nt_tuned(mode, A, W, M, N, K, lda, ldw, ep, nullptr, nullptr, st);
+}
+extern "C" int uvit_op_gemm_nt_sched(int mode, const void* A, const void* W, int M, int N, int K, int lda, int ldw,
+                                     const uvit_gemm_epilogue* ep, const uvit_tuning* tune, uint32_t* tile_counters, uvit_stream st) {
+    if (!ep || !A || !W || !ep->out) return UVIT_ERR_ARG;
+    GemmTune tu;
+    const int trc = tune_from_abi(tune, tu);
+    if (trc) return trc;
+    GemmEpi g = epi_from_abi(ep);
+    g.tile_counter = tile_counters;
+    return uvit_gemm_nt_launch(mode, A, W, M, N, K, lda, ldw, &g, S(st), &tu, nullptr);
 }
 extern "C" int uvit_op_wgrad_group(const uvit_wgrad_problem* problems, int count, const uvit_tuning* tune, uvit_stream st) {
     if (!problems || count < 1 || count > UVIT_TN_GROUP_MAX) return UVIT_ERR_ARG;

@@ -557,12 +557,45 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
                 }
         }
     };
-    int vb = blockIdx.x;
+    // Tile assignment of the persistent form.  Fixed stride (tile_counter == nullptr): tiles blockIdx.x, + gridDim.x, ...  Dynamic
+    // (round 4): XCD x = blockIdx.x % 8 owns the virtual ids x, x + 8, x + 16, ... and every workgroup takes the next unclaimed one of
+    // ITS XCD from a per-XCD counter, one tile ahead of the one it computes (the operand pipeline prefetches across tiles).  With all
+    // CUs present nothing changes; with CUs held by somebody else (RCCL's channel workgroups in a data-parallel run) the workgroups
+    // that start late find few tiles left instead of a full fixed share, and the launch takes tiles / CUs longer, not twice as long.
+    // (the ticket crosses the workgroup through the first word of the epilogue staging area, which is idle between two epilogues: the
+    //  kernel's 160 KiB of dynamic LDS are the whole LDS of the CU, there is no room for a static word)
+    volatile int* const s_ticket = (volatile int*)(smem + (PERSIST ? T_LDS_BYTES : 0));
+    unsigned* const tcnt = PERSIST ? epi.tile_counter : nullptr;
+    const int xcd = blockIdx.x & 7;
+    auto claim = [&]() -> int {                        // thread 0 only: the next virtual tile id of this XCD (may be >= ntiles)
+        return xcd + 8 * (int)__hip_atomic_fetch_add(tcnt + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int vb = blockIdx.x, vb_next = blockIdx.x + (int)gridDim.x;
+    if constexpr (PERSIST) {
+        if (tcnt) {
+            if (tid == 0) { *s_ticket = claim(); }
+            __syncthreads();
+            vb = *s_ticket;
+            __syncthreads();
+            if (tid == 0) { *s_ticket = claim(); }
+            __syncthreads();
+            vb_next = *s_ticket;
+            __syncthreads();
+            if (vb >= ntiles) {                        // nothing left for this workgroup (it started late): leave through the exit counter
+                if (tid == 0) {
+                    const unsigned d = __hip_atomic_fetch_add(tcnt + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d == gridDim.x - 1) for (int i = 0; i < 9; ++i) __hip_atomic_store(tcnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
+        }
+    }
     int m0, n0;
     tile_origin(vb, m0, n0);
     TileSrc cur, nxt;
     tile_src(m0, n0, cur);
     nxt = cur;
+    int pending = -1;                                  // thread 0: the claim issued at the top of the previous tile (for the tile after next)
     const int nk = K / BK;
     int par = 0;                                       // LDS buffer of the current tile's K-tile 0 (alternates when nk is odd)
     bool more = false;                                 // this workgroup has another tile after the current one
@@ -631,8 +664,8 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 
     for (;;) {
         if constexpr (PERSIST) {
-            more = vb + (int)gridDim.x < ntiles;
-            if (more) { int m1, n1; tile_origin(vb + gridDim.x, m1, n1); tile_src(m1, n1, nxt); }
+            more = vb_next < ntiles;
+            if (more) { int m1, n1; tile_origin(vb_next, m1, n1); tile_src(m1, n1, nxt); }
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -720,6 +753,10 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
         if constexpr (PERSIST) {
             // the next tile's K-tile 0 + AL1 BL1 were issued during the last two K-tiles: land them BEFORE the first store
             VM_WAIT(0);
+            // the claim for the tile after next: issued HERE, behind the drain and in front of the epilogue's stores, and read at the top
+            // of the next tile.  (Issued at the top of a tile it sat in wave 0's in-order vmcnt queue in front of the K loop's counted
+            // waits, which then waited for an L2 atomic's round trip: +0.8 % on the step.)
+            if (tcnt && tid == 0) pending = more ? claim() : ntiles;
             GSTAMP_P(seq, 4);
             EPI_RUN_B(MODE, 2 * MT, smem + T_LDS_BYTES + wave * TP_EPI_BYTES, n0 + wn * 64, ACC1, MB1, TP_EPI_BYTES);
         } else {
@@ -730,7 +767,14 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #undef MB1
         GSTAMP(3); GSTAMP_P(seq, 3);
         if (!PERSIST || !more) break;
-        vb += gridDim.x;
+        if (tcnt) {
+            if (tid == 0) *s_ticket = pending;
+            __syncthreads();
+            vb = vb_next; vb_next = *s_ticket;
+            __syncthreads();
+        } else {
+            vb = vb_next; vb_next += (int)gridDim.x;
+        }
         tile_origin(vb, m0, n0);
         cur = nxt;
         par ^= nk & 1;
@@ -738,6 +782,12 @@ void gemm_nt256_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, i
 #ifdef GEMM_STAMP
         ++seq;
 #endif
+    }
+    if constexpr (PERSIST) {
+        if (tcnt && tid == 0) {                        // last workgroup out puts the counters back to zero for the next launch on this stream
+            const unsigned d = __hip_atomic_fetch_add(tcnt + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1) for (int i = 0; i < 9; ++i) __hip_atomic_store(tcnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #undef LOAD_A
 #undef LOAD_B

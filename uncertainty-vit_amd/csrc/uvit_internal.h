@@ -28,6 +28,9 @@ struct GemmEpi {
     // are padding and write nothing
     const int* rowmap = nullptr;
     const int* rowcount = nullptr;
+    // persistent 256x256 kernel: 16 zero-initialised counters (8 per-XCD tile counters, 1 exit counter) in device memory -> the workgroups
+    // take their tiles from the counters instead of by a fixed stride (nullptr: fixed stride); the last workgroup to leave zeroes them again
+    unsigned* tile_counter = nullptr;
 };
 
 // gemm.hip

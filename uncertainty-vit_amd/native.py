@@ -117,6 +117,7 @@ _PROTOTYPES = {
     "uvit_engine_profile_read_kind": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "uvit_op_gemm_nt": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "uvit_op_gemm_nt_tuned": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "uvit_op_gemm_nt_sched": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "uvit_op_gemm_tn": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "uvit_op_wasserstein_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "uvit_op_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _u32, _u32, _vp]),
