@@ -274,11 +274,12 @@ def main():
     x, mask = synthetic_batch(a.batch, 1000 + rank, dev)
     mask = mask.reshape(a.batch, -1).contiguous()
     L = lib()
-    if os.environ.get("UVIT_TN_TARGET") or os.environ.get("UVIT_GEMM_VARIANT"):     # tuning experiments only
+    if os.environ.get("UVIT_TN_TARGET") or os.environ.get("UVIT_GEMM_VARIANT") or os.environ.get("UVIT_WG_CHUNKS"):     # tuning experiments only
         from uncertainty_vit_amd.native import Tuning
         tu = Tuning.default()
         tu.tn_split_target = int(os.environ.get("UVIT_TN_TARGET", tu.tn_split_target))
         tu.nt_variant = int(os.environ.get("UVIT_GEMM_VARIANT", tu.nt_variant))
+        tu.wgrad_group_chunks = int(os.environ.get("UVIT_WG_CHUNKS", tu.wgrad_group_chunks))
         check(L.uvit_engine_set_tuning(engine.h, C.byref(tu)), "set_tuning")
     seed = 1000 + rank             # run_cyclical.py:315 seeds with seed + rank: every rank draws its own dropout / drop-path masks
 
