@@ -12,6 +12,7 @@
 // consecutive output columns of one output row -> 8/16-byte vector epilogue loads and stores.
 // Epilogues fuse bias, GELU, LayerScale*DropPath*residual, GELU', mask-token blend.
 #include <mutex>
+#include <cstdlib>
 
 #include "common.h"
 #include "uvit_internal.h"
@@ -1366,7 +1367,12 @@ int uvit_gemm_nt_launch(int mode, const void* A, const void* W, int M, int N, in
     // 320-row kernel no longer spills inside its K loop; ViT-L at bs = 64 gives 160 such tiles on 256 CUs and stays on the ring)
     const long tiles5 = (long)((M + 319) / 320) * (N / 256 > 0 ? N / 256 : 1);
     const bool one_full_round5 = shape_ok && tiles5 <= g_num_cu && tiles5 * 100 >= (long)g_num_cu * 85;
-    const bool auto_ring = nt_variant == 3 && mode == EPI_RESID && ring_ok && N <= 1024 && M >= 160 * 8 && !one_full_round5;
+    // Round 4: auto no longer sends anything to the ring kernel.  Re-measured at the ViT-L shapes it was kept for (tools/bench_gemm.py --cold style,
+    // residual epilogue, M = 12608 / 25216, N = 1024): K = 1024: ring 85.8 / 146.0 us against 67.7 / 117.9 us for the 256-row staggered kernel,
+    // K = 4096: 191.4 / 305.6 against 125.1 / 239.9 us -- the staggered kernel's K loop and epilogue have moved since round 2, the ring's have not
+    // (profiles/round4_gemm_large_resid_variants.txt).  UVIT_AUTO_RING=1 restores the old rule for A/B runs; variants 6 / 7 still select it.
+    static const bool auto_ring_env = getenv("UVIT_AUTO_RING") && getenv("UVIT_AUTO_RING")[0] == '1';
+    const bool auto_ring = auto_ring_env && nt_variant == 3 && mode == EPI_RESID && ring_ok && N <= 1024 && M >= 160 * 8 && !one_full_round5;
     if (((nt_variant == 6 || nt_variant == 7) && ring_ok) || auto_ring) {
         const int rmt = nt_variant == 6 ? 8 : 10;
         const int rgrid = ((M + 16 * rmt - 1) / (16 * rmt)) * (N / R_BN);
