@@ -1558,8 +1558,11 @@ int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const G
         if (cost < best_cost) { best_cost = cost; best_sp = sp; }
     }
     if (group_chunks > 0) best_sp = group_chunks < (nm_max / 4 > 1 ? nm_max / 4 : 1) ? group_chunks : (nm_max / 4 > 1 ? nm_max / 4 : 1);
-    int items; const int L = plan(best_sp, items);
-    if (!stream_ok(L)) return UVIT_ERR_SHAPE;          // (sp = 2 always qualifies when the boundary is half the rows: the engine's stacked layout)
+    int items; int L = plan(best_sp, items);
+    if (!stream_ok(L)) {                               // a forced chunk count that would straddle the stream boundary: the 2-chunk plan always
+        best_sp = 2; L = plan(best_sp, items);         // qualifies (uvit_gemm_tn_group_ok checked that the boundary is half the K-tiles)
+        if (!stream_ok(L)) return UVIT_ERR_SHAPE;
+    }
     G.max_chunks = 0;
     for (int i = 0; i < n; ++i) {
         G.p[i].chunk_steps = L;
