@@ -179,6 +179,12 @@ int uvit_engine_set_tuning(uvit_engine* e, const uvit_tuning* t);
  * host mirror selects it for single-GPU runs only); dual = 0: everything on the caller's stream (used to time one
  * kernel in isolation).  Environment UVIT_SINGLE_STREAM=1 selects 0 at engine creation. */
 int uvit_engine_set_streams(uvit_engine* e, int dual);
+/* on = 1 (default): a training step of the base model runs every Block branch on the samples its DropPath KEPT (timm drop_path,
+ * modeling_finetune.py:51-62: a dropped sample's branch is multiplied by 0 in the forward and receives no gradient), in compact rows
+ * sized by the host from the same counter-based hash the device draws with; on = 0: every branch runs all samples and the dropped ones
+ * are multiplied by 0, as the reference does.  Same results either way (bench.py reports both rates).  Environment UVIT_DP_ROWS=0
+ * selects 0 at engine creation. */
+int uvit_engine_set_drop_path_rows(uvit_engine* e, int on);
 /* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
  * fused bias+GELU, gemm_nt256_kernel<EPI_GELU / EPI_GELU_DG>) with HIP events on the stream it runs on.
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */

@@ -368,3 +368,41 @@ def test_batch_and_instance_norm_target_variants(golden_dir, case):
         if key in fx:
             g, r = grads[n].float().cpu().double(), torch.from_numpy(np.asarray(fx[key])).double()
             assert (g - r).norm() <= 2e-2 * r.norm(), (n, float((g - r).norm() / r.norm()))
+
+
+@pytest.mark.parametrize("shape", ["tiny", "vitb8", "vitb32_hint"])
+def test_drop_path_sample_lists_equal_all_samples(shape):
+    """uvit_engine_set_drop_path_rows (include/uvit.h): a Block branch whose DropPath dropped a sample is multiplied by 0 for it in the
+    forward and receives no gradient (modeling_finetune.py:51-62, 295-298), so the step runs each branch on the kept samples only, in compact
+    rows.  Same model, batch and seeds with the lists on and off: same loss, same gradients (the weight gradients sum the same non-zero rows in
+    another order), same targets.  `tiny` has ungrouped wgrads and 10-token samples (compact row counts that are no multiple of 64),
+    `vitb8` is ViT-B/16 with drop_path 0.5 (a third of the samples dropped per branch on average), `vitb32_hint` adds the masked-row last
+    block (n_rows_hint), whose MLP keeps its own row list while the layers below run the sample lists."""
+    if shape == "tiny":
+        cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=4, num_heads=2, init_values=0.1, drop_path_rate=0.5, attn_drop_rate=0.1)
+        B, img, P, nm, tl = 12, 48, 9, 4, [2, 3]
+    else:
+        cfg = vo.VitConfig(init_values=0.1, drop_path_rate=0.5, attn_drop_rate=0.05)
+        B, img, P, nm, tl = (8 if shape == "vitb8" else 32), 224, 196, 75, list(range(6, 12))
+    x = closed_form_images("dplists/" + shape, B, img)
+    mask = exact_masks(B, P, nm, 11)
+    res = {}
+    for mode in ("all", "lists"):
+        model, _ = native_model(cfg)
+        model.drop_path_rows = mode == "lists"
+        ema, opt = native_trainer(model)
+        model.train()
+        torch.manual_seed(4321)
+        batch = (x, mask) if shape == "vitb32_hint" else (x.cuda(), mask.cuda())
+        sts = native_steps(model, ema, opt, [batch], tl, start=3)
+        grads = {n: q.grad.detach().float().cpu().clone() for n, q in model.named_parameters()}
+        sts += native_steps(model, ema, opt, [batch], tl, start=4)          # other draws, on the updated weights
+        res[mode] = (sts, grads, {n: q.detach().float().cpu().clone() for n, q in model.named_parameters()})
+        assert model._engine.drop_path_rows == (mode == "lists")
+    (sa, ga, pa), (sl, gl, pl) = res["all"], res["lists"]
+    assert sl[0]["loss"] == pytest.approx(sa[0]["loss"], rel=2e-5) and sl[0]["grad_norm"] == pytest.approx(sa[0]["grad_norm"], rel=2e-4)
+    assert_grads_close(gl, ga, max_tol=2e-3, l2_tol=2e-3, what="[drop-path lists vs all samples] ")
+    # second step: AdamW's first update is lr * sign(g), so the summation-order noise on near-zero gradients moves a few weights by 2 lr
+    assert sl[1]["loss"] == pytest.approx(sa[1]["loss"], rel=1e-3) and sl[1]["grad_norm"] == pytest.approx(sa[1]["grad_norm"], rel=2e-2)
+    for n in ("blocks.1.mlp.fc1.weight", "blocks.2.attn.proj.weight", "blocks.0.norm1.weight"):
+        torch.testing.assert_close(pl[n], pa[n], rtol=0, atol=2 * 2e-3 * 2 + 1e-6)     # two AdamW steps: a sign flip on a ~0 gradient is 2 lr apart

@@ -116,10 +116,10 @@ __device__ __forceinline__ float group_max4(float v) {
 }
 
 #ifdef ATTN_DEBUG
-int uvit_attn_fwd_launch(const void*, const float*, void*, float*, int, int, int, int, float, float, uint32_t, uint32_t, hipStream_t);
+int uvit_attn_fwd_launch(const void*, const float*, void*, float*, int, int, int, int, float, float, uint32_t, uint32_t, hipStream_t, const int*);
 extern "C" int uvit_debug_attn_fwd(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP, float scale,
                                    float p_drop, void* stream) {
-    return uvit_attn_fwd_launch(qkv, biasP, out, lse, B, H, N, NP, scale, p_drop, 1u, 0u, (hipStream_t)stream);
+    return uvit_attn_fwd_launch(qkv, biasP, out, lse, B, H, N, NP, scale, p_drop, 1u, 0u, (hipStream_t)stream, nullptr);
 }
 #endif
 
@@ -130,7 +130,7 @@ template <int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(NW * 64, 4)      // two 7-wave workgroups per CU need <= 128 VGPRs
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ biasP, bf16* __restrict__ out,
                      float* __restrict__ lse, int H, int N, int NP, float scale, uint32_t drop_thr,
-                     float inv_keep, uint32_t drop_key, int ncu) {
+                     float inv_keep, uint32_t drop_key, int ncu, const int* __restrict__ bmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + IMG_BYTES;
@@ -140,6 +140,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
     const int C = H * HD;
     const size_t ld = 3 * (size_t)C;
     const bf16* base = qkv + (size_t)b * N * ld + h * HD;
+    const uint32_t bh_rng = (uint32_t)__builtin_amdgcn_readfirstlane(bmap ? bmap[b] * H + h : bh);
     // Two workgroups share a CU and start together: left alone they load their images together and compute together.  The
     // second workgroup of every CU (first round only: ids ncu .. 2 ncu - 1) starts 8k cycles late, so that from then on one
     // workgroup's image load runs under the other's tile loop (59 -> 55.5 us without dropout, 66 -> 61.6 us with).
@@ -222,7 +223,9 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bia
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+        // bh_rng (drop-path sample lists): sample slot b of a COMPACT batch is sample bmap[b] of the step's batch -- the dropout draws are
+        // indexed by the sample, so a compacted launch draws what the dense one does
+        const uint32_t rowpair = (bh_rng * N + q) * (uint32_t)(NP >> 1);
 #pragma unroll
         for (int ks = 0; ks < (NT_MAX + 1) / 2; ++ks) {
             if (ks < nt2) {
@@ -303,11 +306,11 @@ extern "C" int uvit_debug_attn_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : -3;
 }
 int uvit_attn_bwd_fused_launch(const void*, const void*, const void*, const float*, const float*, float*, void*, void*, int, int, int, int,
-                               int, float, float, uint32_t, uint32_t, hipStream_t);
+                               int, float, float, uint32_t, uint32_t, hipStream_t, const int*);
 extern "C" int uvit_debug_attn_bwd_fused(const void* qkv, const void* o, const void* d_o, const float* biasP, const float* lse, float* delta,
                                          void* dqkv, void* ds_ws, float* slab, int B, int H, int N, float p_drop, void* stream) {
     (void)slab;
-    return uvit_attn_bwd_fused_launch(qkv, o, d_o, biasP, lse, delta, dqkv, ds_ws, ds_ws != nullptr, B, H, N, 208, 0.125f, p_drop, 1u, 0u, (hipStream_t)stream);
+    return uvit_attn_bwd_fused_launch(qkv, o, d_o, biasP, lse, delta, dqkv, ds_ws, ds_ws != nullptr, B, H, N, 208, 0.125f, p_drop, 1u, 0u, (hipStream_t)stream, nullptr);
 }
 #else
 #define ASTAMP(k)
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(FB_WAVES * 64)
 void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                            const float* __restrict__ biasP, const float* __restrict__ lse, float* __restrict__ delta,
                            bf16* __restrict__ dqkv, bf16* __restrict__ ds_out, int H, int N, int NP, float scale,
-                           uint32_t drop_thr, float inv_keep, uint32_t drop_key) {
+                           uint32_t drop_thr, float inv_keep, uint32_t drop_key, const int* __restrict__ bmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kimg = smem;
     char* const vimg = smem + FB_IMG;
@@ -386,7 +389,8 @@ void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict_
             if (g == 0) delta[(size_t)bh * N + q] = dl;
         }
     }
-    const uint32_t rowpair = ((uint32_t)bh * N + q) * (uint32_t)(NP >> 1);
+    const uint32_t bh_rng = (uint32_t)__builtin_amdgcn_readfirstlane(bmap ? bmap[b] * H + h : bh);     // (compact batch: see the forward)
+    const uint32_t rowpair = (bh_rng * N + q) * (uint32_t)(NP >> 1);
     const float cs = scale * LOG2E;
     const float* brow = HAS_BIAS ? biasP + ((size_t)h * NP + (q < NP ? q : NP - 1)) * NP + 4 * g : nullptr;
     // the bias tiles of a step are requested one step ahead
@@ -672,15 +676,15 @@ static int attn_check(int B, int H, int N, int head_dim) {
 }
 
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
-                         float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
+                         float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s, const int* bmap) {
     int rc = attn_check(B, H, N, HD); if (rc) return rc;
     attn_init_once();
     const uint32_t thr = p_drop > 0.f ? uvit_drop_threshold16(p_drop) : 0u;
     const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     if (biasP) hipLaunchKernelGGL((attn_fwd_kernel<FWD_WAVES, true>), dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
-                                  biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer), g_attn_ncu);
+                                  biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer), g_attn_ncu, bmap);
     else hipLaunchKernelGGL((attn_fwd_kernel<FWD_WAVES, false>), dim3(B * H), dim3(FWD_WAVES * 64), 2 * IMG_BYTES, s, (const bf16*)qkv,
-                            biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer), g_attn_ncu);
+                            biasP, (bf16*)out, lse, H, N, NP, scale, thr, inv_keep, uvit_layer_key(seed, layer), g_attn_ncu, bmap);
     return uvit_check_launch();
 }
 
@@ -692,7 +696,7 @@ size_t uvit_attn_bwd_fused_ws_bytes(int B, int H, int N) {
 // ds_ws: bf16 workspace of uvit_attn_bwd_fused_ws_bytes(B, H, N) bytes, written when want_ds != 0 (the bias gradient needs it)
 int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                                float* delta, void* dqkv, void* ds_ws, int want_ds, int B, int H, int N, int NP, float scale,
-                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s) {
+                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s, const int* bmap) {
     int rc = attn_check(B, H, N, HD); if (rc) return rc;
     if (NP < NT_MAX * 16 || (want_ds && !ds_ws)) return UVIT_ERR_ARG;
     attn_init_once();
@@ -701,7 +705,7 @@ int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d
     const uint32_t key = uvit_layer_key(seed, layer);
     bf16* dsw = want_ds ? (bf16*)ds_ws : nullptr;
 #define FB_ARGS dim3(B * H), dim3(FB_WAVES * 64), FB_LDS, s, (const bf16*)qkv, (const bf16*)o_fwd, (const bf16*)d_o, biasP, lse, delta, \
-        (bf16*)dqkv, dsw, H, N, NP, scale, thr, inv_keep, key
+        (bf16*)dqkv, dsw, H, N, NP, scale, thr, inv_keep, key, bmap
     if ((N + 15) / 16 == NT_MAX) {
         if (biasP) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, NT_MAX>), FB_ARGS); else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, NT_MAX>), FB_ARGS);
     } else {

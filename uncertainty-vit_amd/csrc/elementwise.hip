@@ -315,6 +315,38 @@ __global__ void droppath_kernel(float* __restrict__ scales, const float* __restr
     scales[i] = v;
 }
 
+// Drop-path sample lists (round 4).  A branch whose sample drew scale 0 contributes exactly nothing to the forward (x + 0 * branch) and receives
+// exactly no gradient (modeling_finetune.py:51-62, 295-298), so the step runs every branch on the KEPT samples only, in compact buffers.  One
+// workgroup per (layer, branch) list turns the step's multipliers into:  pos[b] = compact slot of sample b or -1;  bmap[slot] = sample;
+// rows[r] = residual-stream row of compact row r (slot * tokens + t -> bmap[slot] * tokens + t; -1 on the pad rows up to the next multiple of
+// 64);  cnt = kept rows.  The host sized the launches from ITS evaluation of the same hash (engine.hip): a list whose count differs from the
+// host's raises a flag behind the counts, which poisons the step's loss (droppath_lists_guard_kernel).
+#define DP_MAX_LISTS 128                     // 2 x UVIT_MAX_DEPTH (include/uvit.h)
+struct DpHostCounts { int k[DP_MAX_LISTS]; };
+__global__ __launch_bounds__(256)
+void droppath_lists_kernel(const float* __restrict__ scales, int* __restrict__ pos, int* __restrict__ bmap, int* __restrict__ rows,
+                           int* __restrict__ cnt, int B, int tokens, int rows_stride, DpHostCounts host) {
+    const int lb = blockIdx.x;
+    const float* sc = scales + (size_t)lb * B;
+    int* p = pos + (size_t)lb * B; int* m = bmap + (size_t)lb * B; int* r = rows + (size_t)lb * rows_stride;
+    __shared__ int s_k;
+    if (threadIdx.x == 0) {
+        int k = 0;
+        for (int b = 0; b < B; ++b) { if (sc[b] != 0.f) { p[b] = k; m[k] = b; ++k; } else p[b] = -1; }
+        for (int b = k; b < B; ++b) m[b] = 0;
+        cnt[lb] = k * tokens;
+        cnt[gridDim.x + lb] = k != host.k[lb];            // checked by droppath_lists_guard_kernel once the loss has been zeroed
+        s_k = k;
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int n = s_k * tokens, npad = (n + 63) & ~63;
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        const int slot = i / tokens;
+        r[i] = i < n ? m[slot] * tokens + (i - slot * tokens) : -1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -402,6 +434,24 @@ int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int total_tile
 }
 int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step, hipStream_t s) {
     hipLaunchKernelGGL(droppath_kernel, dim3((depth * nbr * B + 255) / 256), dim3(256), 0, s, scales, rates_dev, depth, nbr, B, seed, step);
+    return uvit_check_launch();
+}
+
+__global__ void droppath_lists_guard_kernel(const int* __restrict__ flags, int n, float* __restrict__ loss) {
+    int bad = 0;
+    for (int i = 0; i < n; ++i) bad |= flags[i];
+    if (bad) loss[0] = __builtin_nanf("");
+}
+int uvit_droppath_lists_guard_launch(const int* cnt, int nlists, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(droppath_lists_guard_kernel, dim3(1), dim3(1), 0, s, cnt + nlists, nlists, loss);
+    return uvit_check_launch();
+}
+int uvit_droppath_lists_launch(const float* scales, int* pos, int* bmap, int* rows, int* cnt, int nlists, int B, int tokens,
+                               int rows_stride, const int* host_counts, hipStream_t s) {
+    if (nlists < 1 || nlists > DP_MAX_LISTS || rows_stride < ((B * tokens + 63) & ~63)) return UVIT_ERR_ARG;
+    DpHostCounts h;
+    for (int i = 0; i < DP_MAX_LISTS; ++i) h.k[i] = i < nlists ? host_counts[i] : 0;
+    hipLaunchKernelGGL(droppath_lists_kernel, dim3(nlists), dim3(256), 0, s, scales, pos, bmap, rows, cnt, B, tokens, rows_stride, h);
     return uvit_check_launch();
 }
 

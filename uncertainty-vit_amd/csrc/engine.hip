@@ -154,6 +154,13 @@ struct uvit_engine {
     float *dXa, *dXb;
     bf16 *dY1[2], *dY2[2], *dH[2], *dLN, *dAttn, *dqkv[2];   // [layer parity]: read by the wgrad stream while the next layer runs
     float *dp_scales, *dp_rates;
+    // drop-path sample lists (base model, training step): per (layer, branch) list lb = 2 l + branch
+    int *dpl_pos = nullptr, *dpl_bmap = nullptr, *dpl_rows = nullptr, *dpl_cnt = nullptr;
+    size_t dpl_stride = 0;                 // ints per rows list
+    int dpl_K[2 * UVIT_MAX_DEPTH] = {};    // kept samples per list, from the host's evaluation of the drop-path hash
+    bool dpl_enable = true;                // uvit_engine_set_drop_path_rows
+    bool dpl_on = false;                   // the current step runs with lists
+    std::vector<float> dp_rates_host;
     float *loss, *gnorm; double* sumsq;
     float* wl_scratch;     // Wasserstein loss: scalars + per-row distances
     float *dense_v, *dense_acc; int *idrows, *idcount;   // dense target builder (batch / instance-norm target variants)
@@ -232,6 +239,11 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     }
     e->dLN = b.take<bf16>(Mp * C); e->dAttn = b.take<bf16>(Mp * C);
     e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->S * e->B); e->dp_rates = b.take<float>(c.depth);
+    if (e->S == 1) {
+        e->dpl_stride = roundup((size_t)e->B * e->N, 64);
+        e->dpl_pos = b.take<int>((size_t)c.depth * 2 * e->B); e->dpl_bmap = b.take<int>((size_t)c.depth * 2 * e->B);
+        e->dpl_rows = b.take<int>((size_t)c.depth * 2 * e->dpl_stride); e->dpl_cnt = b.take<int>((size_t)c.depth * 4 + 64);    // counts, then the host-mismatch flags
+    }
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->wl_scratch = b.take<float>(16 + BPp);
     e->poisoned = b.take<int>(64);
@@ -328,6 +340,8 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     std::vector<float> rates(cfg->depth);
     for (int i = 0; i < cfg->depth; ++i)
         rates[i] = cfg->depth > 1 ? (float)((double)cfg->drop_path_rate * i / (cfg->depth - 1)) : 0.f;
+    e->dp_rates_host = rates;
+    if (const char* v = getenv("UVIT_DP_ROWS")) e->dpl_enable = v[0] != '0';     // A/B switch (uvit_engine_set_drop_path_rows)
     // transposed-copy descriptors
     std::vector<TransposeDesc> td;
     int tiles = 0;
@@ -424,6 +438,12 @@ extern "C" int uvit_engine_set_streams(uvit_engine* e, int dual) {
     return UVIT_OK;
 }
 
+extern "C" int uvit_engine_set_drop_path_rows(uvit_engine* e, int on) {
+    if (!e) return UVIT_ERR_ARG;
+    e->dpl_enable = on != 0;
+    return UVIT_OK;
+}
+
 extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches) {
     if (!e) return UVIT_ERR_ARG;
     if (enable && e->prof_ev.empty()) {
@@ -501,12 +521,48 @@ static const float* dp_ptr(uvit_engine* e, bool on, int l, int st, int branch, i
     return e->dp_scales + (size_t)(nbr * l + k) * Bc;
 }
 
+// Drop-path sample lists (base model, training step with drop_path > 0; round 4).  A branch that dropped a sample adds exactly 0 for it in the
+// forward and sends exactly 0 back (timm drop_path: x / keep * mask, modeling_finetune.py:51-62), so each branch of the student runs on its
+// KEPT samples only: the LayerNorm in front gathers them into compact rows (and copies the dropped samples' rows to the branch's output
+// stream), the Linears / the attention core run K * tokens rows, the residual epilogue scatters through the row list, and backward mirrors it.
+// The host evaluates the same integer hash as droppath_kernel to size the launches; the lists themselves are built on the device.
+struct DpList { const int *pos, *bmap, *rows, *cnt; int K; };
+static bool dp_list(const uvit_engine* e, int l, int branch, DpList& d) {
+    if (!e->dpl_on) return false;
+    const int lb = 2 * l + branch, K = e->dpl_K[lb];
+    if (K <= 0 || K >= e->B) return false;               // nobody dropped: the dense launches; everybody dropped: dense too (0 * branch)
+    d.pos = e->dpl_pos + (size_t)lb * e->B; d.bmap = e->dpl_bmap + (size_t)lb * e->B;
+    d.rows = e->dpl_rows + (size_t)lb * e->dpl_stride; d.cnt = e->dpl_cnt + lb; d.K = K;
+    return true;
+}
+static int dp_lists_begin(uvit_engine* e, uint32_t seed, uint32_t it, int Bc, hipStream_t s) {
+    const int depth = e->cfg.depth, nbr = 2;
+    bool any = false;
+    for (int l = 0; l < depth; ++l)
+        for (int br = 0; br < nbr; ++br) {
+            const float r = e->dp_rates_host[l];
+            int K = Bc;
+            if (r > 0.f) {                                 // droppath_kernel, on the host
+                const uint32_t key = uvit_hash32(seed ^ ((it * (uint32_t)nbr * depth + (uint32_t)nbr * l + br + 1u) * 0x9E3779B9u));
+                const uint32_t thr = uvit_drop_threshold(r);
+                K = 0;
+                for (int b = 0; b < Bc; ++b) K += uvit_hash32((uint32_t)b ^ key) >= thr ? 1 : 0;
+            }
+            e->dpl_K[nbr * l + br] = K;
+            any = any || (K > 0 && K < Bc);
+        }
+    e->dpl_on = any;
+    if (!any) return UVIT_OK;
+    return uvit_droppath_lists_launch(e->dp_scales, e->dpl_pos, e->dpl_bmap, e->dpl_rows, e->dpl_cnt, nbr * depth, Bc, e->N,
+                                      (int)e->dpl_stride, e->dpl_K, s);
+}
+
 // R > 0 (base model, student's last block of a training step): the MLP branch runs on the R compact rows of the masked-patch list only --
 // LN2 gathers them, fc1 / fc2 are R-row GEMMs and the residual epilogue of fc2 reads x_mid and writes x_out / the saved branch output at the
 // listed rows (the other rows of x_out are never read: the head and the final-norm backward go through the same list).
 static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x_in, float* x_mid, float* x_out,
                          LayerActs& a, bool save, const float* biasP, bool dp_on, float pdrop, uint32_t seed, int Bc,
-                         hipStream_t s, int R = 0) {
+                         hipStream_t s, int R = 0, bool lists = false) {
     const LayerOff& o = e->lo.L[l];
     const int M = Bc * e->N, C = e->C, Hd = e->Hd, S = e->S;
     const size_t Mp = e->Mpad;                                   // row offset of stream 1
@@ -514,14 +570,21 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     // counters of the persistent GEMMs' dynamic tile assignment: one block per stream (the teacher and student forwards run side by side)
     static const bool dyn_tiles = !(getenv("UVIT_DYN_TILES") && getenv("UVIT_DYN_TILES")[0] == '0');     // A/B switch
     unsigned* const tcnt = (e->tile_cnt && dyn_tiles) ? e->tile_cnt + ((e->dual && s == e->aux) ? 16 : 0) : nullptr;
-    CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, Mall, C, e->cfg.ln_eps, s));
+    // drop-path sample lists of the two branches (S == 1, not the masked-row last block): Ma / Mm rows instead of M
+    DpList da{}, dm{};
+    const bool la = lists && R == 0 && S == 1 && Bc == e->B && dp_list(e, l, 0, da);
+    const bool lm = lists && R == 0 && S == 1 && Bc == e->B && dp_list(e, l, 1, dm);
+    const int Ma = la ? da.K * e->N : M;
+    if (la) CHECK(uvit_ln_fwd_keep_launch(x_in, da.pos, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, x_mid, M, C, e->N, e->cfg.ln_eps, s));
+    else CHECK(uvit_ln_fwd_launch(x_in, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, Mall, C, e->cfg.ln_eps, s));
     for (int st = 0; st < S; ++st) {     // same qkv.weight for both streams (modeling_finetune_dist.py:121,127)
         GemmEpi q; q.out = a.qkv + st * Mp * 3 * C; q.bias = w.f + off_qb(o, st); q.bias2 = w.f + off_vb(o, st); q.ldo = 3 * C;
         q.tile_counter = tcnt;
-        CHECK(GEMM_NT(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, M, 3 * C, C, C, C, &q, s));
+        CHECK(GEMM_NT(st ? EPI_QKV_ELU : EPI_QKV, a.ln1 + st * Mp * C, w.b + o.qkvw, Ma, 3 * C, C, C, C, &q, s));
     }
     if (S == 1) {
-        CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s));
+        CHECK(uvit_attn_fwd_launch(a.qkv, biasP, a.attn, a.lse, la ? da.K : Bc, e->H, e->N, e->NP, 0.125f, pdrop, seed, (uint32_t)l, s,
+                                   la ? da.bmap : nullptr));
     } else {
         CHECK(uvit_attn2_fwd_launch(a.qkv, a.qkv + Mp * 3 * C, biasP, a.attn, a.attn + Mp * C, a.lse, Bc, e->H, e->N, e->NP, 0.125f,
                                     pdrop, seed, (uint32_t)l, s));
@@ -537,23 +600,27 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     for (int st = 0; st < S; ++st) {
         GemmEpi p; p.out = x_mid + st * Mp * C; p.out2 = save ? a.projout + st * Mp * C : nullptr; p.bias = w.f + off_projb(o, st);
         p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
-        const bool pp = prof_begin(UVIT_PROF_PROJ);
-        CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), M, C, C, C, C, &p, s));
+        if (la) { p.rowmap = da.rows; p.rowcount = da.cnt; }
+        const bool pp = !la && prof_begin(UVIT_PROF_PROJ);
+        CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), Ma, C, C, C, C, &p, s));
         prof_end(pp);
     }
+    const int Mm = lm ? dm.K * e->N : (R > 0 ? R : Mall);
     if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
+    else if (lm) CHECK(uvit_ln_fwd_keep_launch(x_mid, dm.pos, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, x_out, M, C, e->N, e->cfg.ln_eps, s));
     else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd; f1.tile_counter = tcnt;
-    const bool prof = R == 0 && prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T);    // (only full-size launches are timed)
+    const bool prof = R == 0 && !lm && prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T);    // (only full-size launches are timed)
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
-    CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, R > 0 ? R : Mall, Hd, C, C, C, &f1, s));
+    CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mm, Hd, C, C, C, &f1, s));
     prof_end(prof);
     for (int st = 0; st < S; ++st) {
         GemmEpi f2; f2.out = x_out + st * Mp * C; f2.out2 = save ? a.mlpout + st * Mp * C : nullptr; f2.bias = w.f + o.fc2b;
         f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
         if (R > 0) { f2.rowmap = e->rowidx; f2.rowcount = e->count; }
-        const bool pf2 = R == 0 && prof_begin(UVIT_PROF_FC2);
-        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, R > 0 ? R : M, C, Hd, Hd, Hd, &f2, s));
+        else if (lm) { f2.rowmap = dm.rows; f2.rowcount = dm.cnt; }
+        const bool pf2 = R == 0 && !lm && prof_begin(UVIT_PROF_FC2);
+        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, R > 0 ? R : (lm ? Mm : M), C, Hd, Hd, Hd, &f2, s));
         prof_end(pf2);
     }
     return UVIT_OK;
@@ -586,6 +653,10 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
     const bool dp_on = dropout && !teacher && e->cfg.drop_path_rate > 0.f;
     const float pdrop = (dropout && !teacher) ? e->cfg.attn_drop_rate : 0.f;
     if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, 2 * e->S, Bc, seed, it, s));
+    if (!teacher) {
+        e->dpl_on = false;
+        if (dp_on && save_student && e->dpl_enable && e->S == 1 && Bc == e->B) CHECK(dp_lists_begin(e, seed, it, Bc, s));
+    }
     const uint32_t aseed = uvit_hash32(seed ^ (it * 0x85EBCA6Bu + 0x1234567u));
     if (!teacher) { e->last_dropout = dropout; e->last_seed = aseed; e->last_it = it; }
     const bool use_saved = !teacher || !hp_targets;   // drop-in forward keeps every layer for either weight set
@@ -596,7 +667,7 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
         if (use_saved) {
             const bool last_compact = save_student && !teacher && l == e->cfg.depth - 1 && e->compact_R > 0;
             CHECK(forward_layer(e, w, l, e->X[l], e->XM[l], e->X[l + 1], e->acts[l], save_student && !teacher, biasP, dp_on,
-                                pdrop, aseed, Bc, s, last_compact ? e->compact_R : 0));
+                                pdrop, aseed, Bc, s, last_compact ? e->compact_R : 0, !teacher && e->dpl_on));
         } else {
             float* xin = e->tX[l & 1]; float* xout = e->tX[(l + 1) & 1];
             // `[targets[i] for i in target_layers]` (engine_for_cyclical.py:92): a layer listed twice is summed twice and the
@@ -763,6 +834,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
         CHECK(uvit_variance_loss_launch(e->outputs[0], e->count, hp->var_w0, hp->var_margin0, ls, e->var_scratch, e->loss, e->loss + 4,
                                         e->dout[0], BP, C, s));
     if (e->compact_R > 0) CHECK(uvit_rows_guard_launch(e->count, e->compact_R, e->loss, s));     // more masked rows than the host promised
+    if (e->dpl_on) CHECK(uvit_droppath_lists_guard_launch(e->dpl_cnt, 2 * e->cfg.depth, e->loss, s));   // a sample list that is not the host's
     if (e->S == 2)
         CHECK(uvit_wasserstein_loss_launch(e->outputs[0], e->outputs[1], e->targets[0], e->targets[1], e->count, hp->lambda_pretraining,
                                            ls, e->wl_scratch, e->loss, e->dout[0], e->dout[1], BP, C, s));
@@ -815,7 +887,14 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     // last block with a masked-row list (see forward_layer): its MLP branch -- LayerScale backward, both dgrads, both wgrads, LN2 backward --
     // runs on the R compact rows; dY1 / dH / dLN are compact, the LN2 backward scatters into the (zeroed) dense dXb / dY2
     const int R = (l == e->cfg.depth - 1) ? e->compact_R : 0;
-    const int Mmlp = R > 0 ? R : Mall, Mmlp_red = R > 0 ? R : Mred;
+    // drop-path sample lists (see forward_layer): the attention branch on Ma = Ka tokens rows, the MLP branch on Km tokens rows; the wgrad
+    // reductions run to the next multiple of 64 (pad rows of the dY operands are zero)
+    DpList da{}, dm{}, dm1{};
+    const bool la = R == 0 && S == 1 && dp_list(e, l, 0, da);
+    const bool lm = R == 0 && S == 1 && dp_list(e, l, 1, dm);
+    const bool lm1 = l > 0 && S == 1 && dp_list(e, l - 1, 1, dm1);          // the MLP branch of the layer below (its LayerScale backward rides here)
+    const int Ma = la ? da.K * e->N : M, Mac = la ? (int)roundup(Ma, 64) : Mred1;
+    const int Mmlp = R > 0 ? R : (lm ? (int)roundup((size_t)dm.K * e->N, 64) : Mall), Mmlp_red = (R > 0 || lm) ? Mmlp : Mred;
     // weight gradients: one grouped launch per layer (bias column sums of fc1 / q / v fused) when every Linear has
     // 256-multiple dimensions; otherwise one launch per Linear as the operands become available
     TnProb wg[UVIT_TN_GROUP_MAX];
@@ -826,9 +905,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         f1.bias = RP(o.fc1b); f1.bias_end = Hd;
         for (int st = 0; st < S; ++st) {
             TnProb& pj = wg[nwg++]; pj.Y = dY2 + st * Mp * C; pj.X = a.attn + st * Mp * C; pj.C = g + off_projw(o, st);
-            pj.M = Mred1; pj.Nn = C; pj.Kk = C; pj.ldy = C; pj.ldx = C; pj.ldc = C;
+            pj.M = Mac; pj.Nn = C; pj.Kk = C; pj.ldy = C; pj.ldx = C; pj.ldc = C;
         }
-        TnProb& qk = wg[nwg++]; qk.Y = dqkv; qk.X = a.ln1; qk.C = g + o.qkvw; qk.M = Mred; qk.Nn = 3 * C; qk.Kk = C; qk.ldy = 3 * C; qk.ldx = C; qk.ldc = C;
+        TnProb& qk = wg[nwg++]; qk.Y = dqkv; qk.X = a.ln1; qk.C = g + o.qkvw; qk.M = la ? Mac : Mred; qk.Nn = 3 * C; qk.Kk = C; qk.ldy = 3 * C; qk.ldx = C; qk.ldc = C;
         qk.bias = RP(off_qb(o, 0)); qk.bias_end = C; qk.bias2 = RP(off_vb(o, 0)); qk.bias2_begin = 2 * C;
         // two-stream: the q / v biases differ per stream while the stacked wgrad reduces over both: the token chunks of stream 1
         // (rows from Mpad on) sum into the covariance stream's biases (round 4; was 4 colsum launches per layer)
@@ -842,6 +921,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     if (R > 0)       // compact dY1 from the residual-stream gradient and the saved branch output at the listed rows (S == 1)
         CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), R, C, e->N, NREP,
                                  e->n_nd, s, e->rowidx, e->count));
+    else if (e->ls_prefused != l && lm)    // compact dY1 of the kept samples (pad rows zero)
+        CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), Mmlp, C, e->N, NREP,
+                                 e->n_nd, s, dm.rows, dm.cnt));
     else if (e->ls_prefused != l)
         for (int st = 0; st < S; ++st)
             CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + st * Mp * C,
@@ -861,7 +943,12 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(GEMM_NT(EPI_BF16, dH, wt + o.fc1w, Mmlp, C, Hd, Hd, Hd, &d2, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
-    if (fuse_ls) {
+    if (la || lm) {
+        // LayerNorm 2 backward (MLP list) + the attention branch's LayerScale backward (attention list) over the dense rows
+        CHECK(uvit_ln_bwd_keep_launch(e->dLN, e->XM[l], lm ? dm.pos : nullptr, a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b),
+                                      a.projout, pf + o.g1, dp_ptr(e, dp_on, l, 0, 0, e->B), dY2, RP(o.g1), RP(off_projb(o, 0)),
+                                      la ? da.pos : nullptr, la ? da.cnt : nullptr, e->N, M, C, NREP, e->n_nd, s));
+    } else if (fuse_ls) {
         for (int st = 0; st < S; ++st) {
             const size_t ro = st * Mp, eo = ro * C;
             CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->XM[l] + eo, a.mean2 + ro, a.rstd2 + ro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
@@ -877,9 +964,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     }
     if (!grouped) CHECK(handoff(2));
     for (int st = 0; st < S; ++st) {
-        if (!grouped) CHECK(GEMM_TN(dY2 + st * Mp * C, a.attn + st * Mp * C, Mred1, C, C, C, C, g + off_projw(o, st), C, 1, ws));
+        if (!grouped) CHECK(GEMM_TN(dY2 + st * Mp * C, a.attn + st * Mp * C, Mac, C, C, C, C, g + off_projw(o, st), C, 1, ws));
         GemmEpi d3; d3.out = e->dAttn + st * Mp * C; d3.ldo = C;
-        CHECK(GEMM_NT(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), M, C, C, C, C, &d3, s));
+        CHECK(GEMM_NT(EPI_BF16, dY2 + st * Mp * C, wt + off_projw(o, st), Ma, C, C, C, C, &d3, s));
     }
     const float* biasP = e->biasP_s;
     float* slabs = e->cfg.use_shared_rel_pos_bias ? e->slabs : nullptr;
@@ -889,8 +976,10 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         // of layer l was last read by the reduction of layer l + 2, which precedes ev_wdone[l + 2] on that stream (waited for above).
         void* dsw = slabs ? e->ds_ws[par] : nullptr;
         if (S == 1) {
-            CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP,
-                                             0.125f, pdrop, e->last_seed, (uint32_t)l, s));
+            // (a compact launch writes Ka samples: the rows up to the wgrad's reduction length are zero-filled here)
+            if (la && Mac > Ma) CHECK(uvit_zero_launch(dqkv + (size_t)Ma * 3 * C, (size_t)(Mac - Ma) * 3 * C * sizeof(bf16), s));
+            CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, la ? da.K : e->B, e->H,
+                                             e->N, e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s, la ? da.bmap : nullptr));
         } else {
             CHECK(uvit_attn2_bwd_launch(a.qkv, a.qkv + Mp * 3 * C, a.attn, a.attn + Mp * C, e->dAttn, e->dAttn + Mp * C, biasP, a.lse,
                                         e->delta, dqkv, dqkv + Mp * 3 * C, dsw, dsw != nullptr, e->B, e->H, e->N, e->NP, 0.125f, pdrop,
@@ -898,7 +987,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         }
         if (dsw) {
             if (e->dual) { HIPCHECK(hipEventRecord(e->ev_ds, s)); HIPCHECK(hipStreamWaitEvent(ws, e->ev_ds, 0)); }
-            if (S == 1) CHECK(uvit_attn_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
+            if (S == 1) CHECK(uvit_attn_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, la ? da.K : e->B, e->H, e->N, e->NP, ws));
             else CHECK(uvit_attn2_dbias_reduce_launch(dsw, slabs, e->slab_started ? 1 : 0, e->B, e->H, e->N, e->NP, ws));
         }
     }
@@ -906,15 +995,25 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     CHECK(handoff(3));
     if (!grouped)
         for (int st = 0; st < S; ++st) {
-            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, M, RP(off_qb(o, st)), NREP, e->n_nd, ws));
-            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, M, RP(off_vb(o, st)), NREP, e->n_nd, ws));
+            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 0, C, Ma, RP(off_qb(o, st)), NREP, e->n_nd, ws));
+            CHECK(uvit_colsum_launch(dqkv + st * Mp * 3 * C, 3 * C, 2 * C, C, Ma, RP(off_vb(o, st)), NREP, e->n_nd, ws));
         }
     if (grouped) CHECK(GEMM_TN_GROUP(wg, nwg, ws));
-    else CHECK(GEMM_TN(dqkv, a.ln1, Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
+    else CHECK(GEMM_TN(dqkv, a.ln1, la ? Mac : Mred, 3 * C, C, 3 * C, C, g + o.qkvw, C, 1, ws));
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
-    CHECK(GEMM_NT(EPI_BF16, dqkv, wt + o.qkvw, Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
-    if (fuse_ls && l > 0) {
+    CHECK(GEMM_NT(EPI_BF16, dqkv, wt + o.qkvw, la ? Ma : Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
+    if (la || lm1) {
+        // LayerNorm 1 backward (attention list) + the LayerScale backward of layer l-1's MLP branch (its list), dense rows
+        if (l > 0 && e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
+        const LayerOff& on = e->lo.L[l > 0 ? l - 1 : 0];
+        CHECK(uvit_ln_bwd_keep_launch(e->dLN, e->X[l], la ? da.pos : nullptr, a.mean1, a.rstd1, pf + o.n1w, e->dXb, e->dXa, RP(o.n1w), RP(o.n1b),
+                                      l > 0 ? e->acts[l - 1].mlpout : nullptr, l > 0 ? pf + on.g2 : nullptr,
+                                      l > 0 ? dp_ptr(e, dp_on, l - 1, 0, 1, e->B) : nullptr, l > 0 ? e->dY1[(l - 1) & 1] : nullptr,
+                                      l > 0 ? RP(on.g2) : nullptr, l > 0 ? RP(on.fc2b) : nullptr, lm1 ? dm1.pos : nullptr, lm1 ? dm1.cnt : nullptr,
+                                      e->N, M, C, NREP, e->n_nd, s));
+        if (l > 0) e->ls_prefused = l - 1;
+    } else if (fuse_ls && l > 0) {
         // the MLP-branch LayerScale backward of layer l-1 writes dY1 of parity (l-1) & 1, last read by the wgrad of layer l+1
         if (e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
         const LayerOff& on = e->lo.L[l - 1];

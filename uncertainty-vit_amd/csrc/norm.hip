@@ -223,6 +223,183 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
     }
 }
 
+// ---- drop-path sample lists (round 4): the same two kernels over a DENSE walk of the residual stream with COMPACT branch buffers ----
+// pos[b] = compact slot of sample b, -1 when the branch dropped it.  Forward: a kept row is normalised into compact row slot * tokens + t;
+// a dropped row is copied to the branch's output stream (x + 0 * branch = x), which the residual epilogue of the branch's last GEMM then
+// does not touch.
+template <int NV>
+__global__ __launch_bounds__(LN_WAVES * 64)
+void ln_fwd_keep_kernel(const float* __restrict__ x, const int* __restrict__ pos, const float* __restrict__ w,
+                        const float* __restrict__ b, bf16* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                        float* __restrict__ xcopy, int M, int C, float eps, int tokens) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    const int smp = row / tokens, slot = pos[smp];
+    RowVec<NV> r;
+    load_row(r, x + (size_t)row * C, C, lane);
+    if (slot < 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) if (lane + 64 * k < nv) ((float4*)(xcopy + (size_t)row * C))[lane + 64 * k] = r.v[k];
+        return;
+    }
+    const size_t crow = (size_t)slot * tokens + (row - smp * tokens);
+    float mean, rstd;
+    row_stats(r, C, lane, eps, mean, rstd);
+    if (lane == 0) { mean_o[crow] = mean; rstd_o[crow] = rstd; }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            const float4 ww = ((const float4*)w)[i], bb = ((const float4*)b)[i];
+            bf16x4 o = {f2bf((r.v[k].x - mean) * rstd * ww.x + bb.x), f2bf((r.v[k].y - mean) * rstd * ww.y + bb.y),
+                        f2bf((r.v[k].z - mean) * rstd * ww.z + bb.z), f2bf((r.v[k].w - mean) * rstd * ww.w + bb.w)};
+            ((bf16x4*)(y + crow * C))[i] = o;
+        }
+    }
+}
+
+// Backward: rows are walked densely.  posA maps the sample to the compact slot of the LayerNorm's own branch (dy, mean, rstd compact;
+// nullptr = every sample kept, dense): a dropped sample's row passes dres through (dx = dres) and adds nothing to dw / db.  posB maps it
+// to the slot of the branch whose LayerScale backward rides along (dy_next compact, y_next dense-indexed; nullptr = dense; ls.dy ==
+// nullptr: no such branch): a dropped sample writes nothing and adds nothing to dgamma / dbias.  The pad rows of dy_next (cntB .. next
+// multiple of 64: the wgrad's reduction length) are zero-filled by the last workgroup.
+template <int NV>
+struct LnkRow {
+    float4 x[NV], dres[NV];
+    bf16x4 dy[NV], y[NV];
+    float mean, rstd, dp;
+    int ca, cb;                     // compact rows of the two branches, -1 = dropped
+};
+
+template <int NV>
+__device__ __forceinline__ void lnk_load(LnkRow<NV>& r, int row, const bf16* dy, const float* x, const int* posA, const int* posB,
+                                         const float* mean_i, const float* rstd_i, const float* dres, const LsNext& ls,
+                                         int C, int nv, int lane) {
+    const int smp = row / ls.tokens, t = row - smp * ls.tokens;
+    const int sa = posA ? posA[smp] : smp, sb = ls.dy ? (posB ? posB[smp] : smp) : -1;
+    r.ca = sa < 0 ? -1 : sa * ls.tokens + t;
+    r.cb = sb < 0 ? -1 : sb * ls.tokens + t;
+    r.mean = 0.f; r.rstd = 0.f; r.dp = 1.0f;
+    if (r.ca >= 0) { r.mean = mean_i[r.ca]; r.rstd = rstd_i[r.ca]; }
+    if (r.cb >= 0 && ls.rowscale) r.dp = ls.rowscale[smp];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            r.dres[k] = ((const float4*)(dres + (size_t)row * C))[i];
+            if (r.ca >= 0) {
+                r.x[k] = ((const float4*)(x + (size_t)row * C))[i];
+                r.dy[k] = ((const bf16x4*)(dy + (size_t)r.ca * C))[i];
+            }
+            if (r.cb >= 0) r.y[k] = ((const bf16x4*)(ls.y + (size_t)row * C))[i];
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(LNB_WAVES * 64)
+void ln_bwd_keep_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, const int* __restrict__ posA,
+                        const int* __restrict__ posB, const int* __restrict__ cntB, const float* __restrict__ mean_i,
+                        const float* __restrict__ rstd_i, const float* __restrict__ w, const float* __restrict__ dres,
+                        float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep,
+                        size_t rep_stride, LsNext ls, int rows_per_block) {
+    __shared__ float red[LNB_WAVES][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = C >> 2;
+    if (ls.dy && posB && blockIdx.x == gridDim.x - 1) {
+        const int n = *cntB, npad = (n + 63) & ~63;
+        for (int r = n + wave; r < npad; r += LNB_WAVES)
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (lane + 64 * k < nv) ((bf16x4*)(ls.dy + (size_t)r * C))[lane + 64 * k] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+    }
+    float4 ww[NV], gm[NV];
+    RowVec<NV> aw, ab, ag, ay;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        aw.v[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab.v[k] = aw.v[k]; ag.v[k] = aw.v[k]; ay.v[k] = aw.v[k]; gm[k] = aw.v[k];
+        ww[k] = lane + 64 * k < nv ? ((const float4*)w)[lane + 64 * k] : aw.v[k];
+        if (ls.dy && lane + 64 * k < nv) gm[k] = ((const float4*)ls.gamma)[lane + 64 * k];
+    }
+    const int row_end = min((int)(blockIdx.x + 1) * rows_per_block, M);
+    int row = blockIdx.x * rows_per_block + wave;
+    LnkRow<NV> cur, nxt;
+    if (row < row_end) lnk_load<NV>(cur, row, dy, x, posA, posB, mean_i, rstd_i, dres, ls, C, nv, lane);
+    for (; row < row_end; row += LNB_WAVES) {
+        const bool more = row + LNB_WAVES < row_end;
+        if (more) lnk_load<NV>(nxt, row + LNB_WAVES, dy, x, posA, posB, mean_i, rstd_i, dres, ls, C, nv, lane);
+        float4 o[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) o[k] = cur.dres[k];
+        if (cur.ca >= 0) {
+            const float mean = cur.mean, rstd = cur.rstd;
+            float4 g[NV], h[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (lane + 64 * k < nv) {
+                    const float d0 = bf2f(cur.dy[k][0]), d1 = bf2f(cur.dy[k][1]), d2 = bf2f(cur.dy[k][2]), d3 = bf2f(cur.dy[k][3]);
+                    h[k] = make_float4((cur.x[k].x - mean) * rstd, (cur.x[k].y - mean) * rstd, (cur.x[k].z - mean) * rstd,
+                                       (cur.x[k].w - mean) * rstd);
+                    aw.v[k].x += d0 * h[k].x; aw.v[k].y += d1 * h[k].y; aw.v[k].z += d2 * h[k].z; aw.v[k].w += d3 * h[k].w;
+                    ab.v[k].x += d0; ab.v[k].y += d1; ab.v[k].z += d2; ab.v[k].w += d3;
+                    g[k] = make_float4(d0 * ww[k].x, d1 * ww[k].y, d2 * ww[k].z, d3 * ww[k].w);
+                    s1 += g[k].x + g[k].y + g[k].z + g[k].w;
+                    s2 += g[k].x * h[k].x + g[k].y * h[k].y + g[k].z * h[k].z + g[k].w * h[k].w;
+                } else {
+                    g[k] = make_float4(0.f, 0.f, 0.f, 0.f); h[k] = g[k];
+                }
+            }
+            s1 = wave_sum(s1) / C;
+            s2 = wave_sum(s2) / C;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                o[k] = make_float4(cur.dres[k].x + rstd * (g[k].x - s1 - h[k].x * s2), cur.dres[k].y + rstd * (g[k].y - s1 - h[k].y * s2),
+                                   cur.dres[k].z + rstd * (g[k].z - s1 - h[k].z * s2), cur.dres[k].w + rstd * (g[k].w - s1 - h[k].w * s2));
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nv) {
+                ((float4*)(dx + (size_t)row * C))[i] = o[k];
+                if (cur.cb >= 0) {
+                    const float e0 = o[k].x * cur.dp, e1 = o[k].y * cur.dp, e2 = o[k].z * cur.dp, e3 = o[k].w * cur.dp;
+                    ag.v[k].x += e0 * bf2f(cur.y[k][0]); ag.v[k].y += e1 * bf2f(cur.y[k][1]);
+                    ag.v[k].z += e2 * bf2f(cur.y[k][2]); ag.v[k].w += e3 * bf2f(cur.y[k][3]);
+                    const bf16x4 ob = {f2bf(e0 * gm[k].x), f2bf(e1 * gm[k].y), f2bf(e2 * gm[k].z), f2bf(e3 * gm[k].w)};
+                    ((bf16x4*)(ls.dy + (size_t)cur.cb * C))[i] = ob;
+                    ay.v[k].x += bf2f(ob[0]); ay.v[k].y += bf2f(ob[1]); ay.v[k].z += bf2f(ob[2]); ay.v[k].w += bf2f(ob[3]);
+                }
+            }
+        }
+        if (more) cur = nxt;
+    }
+    const size_t rep = (size_t)(blockIdx.x % nrep) * rep_stride;
+    auto fold = [&](const float4& part, float* dst, int k) {
+        __syncthreads();
+        ((float4*)red[wave])[lane] = part;
+        __syncthreads();
+        if (lane < 32) {
+            const int col = wave * 32 + lane;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < LNB_WAVES; ++q) sum += red[q][col];
+            const int c = 256 * k + col;
+            if (c < C) atomicAdd(dst + rep + c, sum);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (64 * k < nv) {
+            fold(aw.v[k], dw, k);
+            fold(ab.v[k], db, k);
+            if (ls.dy) { fold(ag.v[k], ls.dgamma, k); fold(ay.v[k], ls.dbias, k); }
+        }
+    }
+}
+
 // acc[i] (+)= layer_norm(x[rowidx[i]] - sub[rowidx[i]])  (no affine; sub == nullptr: 0).  `sub` = the stream before the
 // MLP branch: x - sub is the block's `fc` output, the `--layer_results fc` target (modeling_cyclical.py:199-205).
 template <int NV>
@@ -344,6 +521,24 @@ int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, con
     const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        rowidx, count, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
+    return uvit_check_launch();
+}
+int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, const float* b, void* y, float* mean, float* rstd,
+                            float* xcopy, int M, int C, int tokens, float eps, hipStream_t s) {
+    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !pos || !xcopy || !mean || !rstd) return UVIT_ERR_SHAPE;
+    LN_DISPATCH(ln_fwd_keep_kernel, C, dim3((M + LN_WAVES - 1) / LN_WAVES), dim3(LN_WAVES * 64), 0, s, x, pos, w, b, (bf16*)y, mean, rstd,
+                       xcopy, M, C, eps, tokens);
+    return uvit_check_launch();
+}
+int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
+                            const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
+                            const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
+    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !dres || (posB && (!cntB || !dy_next))) return UVIT_ERR_SHAPE;
+    const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
+    const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
+    LN_DISPATCH(ln_bwd_keep_kernel, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x, posA, posB, cntB, mean, rstd,
+                       w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,

@@ -72,15 +72,16 @@ bool uvit_gemm_tn_group_ok(const TnProb* probs, int n, const GemmTune* tune = nu
 int uvit_gemm_tn_group_launch(const TnProb* probs, int n, hipStream_t s, const GemmTune* tune = nullptr);
 
 // attention.hip
+// bmap != nullptr: the launch runs a COMPACT batch (drop-path sample list); sample slot b draws the dropout of sample bmap[b]
 int uvit_attn_fwd_launch(const void* qkv, const float* biasP, void* out, float* lse, int B, int H, int N, int NP,
-                         float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+                         float scale, float p_drop, uint32_t seed, uint32_t layer, hipStream_t s, const int* bmap = nullptr);
 // fused backward (one recomputation of P; dS leaves as bf16 for the bias gradient): ds_ws holds uvit_attn_bwd_fused_ws_bytes()
 // bytes and is written when want_ds != 0; uvit_attn_dbias_reduce_launch sums it over the batch into ONE [H][NP][NP] slab laid out
 // [h][key][q] (accumulate = 0: the slab is zero-filled first).  Two launches so that the reduction can run on another stream.
 size_t uvit_attn_bwd_fused_ws_bytes(int B, int H, int N);
 int uvit_attn_bwd_fused_launch(const void* qkv, const void* o_fwd, const void* d_o, const float* biasP, const float* lse,
                                float* delta, void* dqkv, void* ds_ws, int want_ds, int B, int H, int N, int NP, float scale,
-                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s);
+                               float p_drop, uint32_t seed, uint32_t layer, hipStream_t s, const int* bmap = nullptr);
 int uvit_attn_dbias_reduce_launch(const void* ds_ws, float* dbias_slab, int accumulate, int B, int H, int N, int NP, hipStream_t s);
 
 // attention2.hip (two-stream Wasserstein attention)
@@ -102,6 +103,13 @@ int uvit_ln_fwd_gather_launch(const float* x, const int* rowidx, const int* coun
 int uvit_ln_bwd_launch(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                        const float* dres, float* dx, float* dw, float* db, int M, int C, int nrep, size_t rep_stride,
                        hipStream_t s);
+// drop-path sample lists (norm.hip): dense walk of the residual stream, compact branch buffers
+int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, const float* b, void* y, float* mean, float* rstd,
+                            float* xcopy, int M, int C, int tokens, float eps, hipStream_t s);
+int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
+                            const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
+                            const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s);
 // LayerNorm backward fused with the LayerScale + DropPath backward of the branch that consumes dx next
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
@@ -145,6 +153,12 @@ int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch_bf1
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int max_tiles, hipStream_t s);
 int uvit_droppath_launch(float* scales, const float* rates_dev, int depth, int nbr, int B, uint32_t seed, uint32_t step,
                          hipStream_t s);
+// drop-path sample lists of a step (elementwise.hip): per (layer, branch) list lb: pos[lb][b], bmap[lb][slot], rows[lb][r] (stride rows_stride,
+// pad rows -1), cnt[lb] = kept rows, cnt[nlists + lb] = 1 when the kept SAMPLES differ from host_counts[lb], what the host sized the launches
+// with; uvit_droppath_lists_guard_launch turns any such flag into a NaN loss
+int uvit_droppath_lists_launch(const float* scales, int* pos, int* bmap, int* rows, int* cnt, int nlists, int B, int tokens,
+                               int rows_stride, const int* host_counts, hipStream_t s);
+int uvit_droppath_lists_guard_launch(const int* cnt, int nlists, float* loss, hipStream_t s);
 int uvit_add_pos_launch(float* x, const float* pos, int B, int N, int C, hipStream_t s);
 int uvit_pos_bwd_launch(const float* dx, float* dpos, int B, int N, int C, hipStream_t s);
 int uvit_synth_batch_launch(float* images, int64_t* mask, int B, int chans, int img_size, int patches, int n_mask, uint32_t seed,

@@ -113,7 +113,15 @@ class NativeEngine:
         if os.environ.get("UVIT_STREAM_MODE"):          # A/B runs
             self.stream_mode = int(os.environ["UVIT_STREAM_MODE"])
         check(L.uvit_engine_set_streams(self.h, self.stream_mode), "set_streams")
+        # drop-path sample lists (include/uvit.h, uvit_engine_set_drop_path_rows): `model.drop_path_rows = False` before the first step, or
+        # set_drop_path_rows(False) later, runs every branch on every sample as the reference does (same results; bench.py's all-rows line)
+        self.drop_path_rows = bool(getattr(model, "drop_path_rows", os.environ.get("UVIT_DP_ROWS", "1") != "0"))
+        self.set_drop_path_rows(self.drop_path_rows)
         self.sync_shadows(3)
+
+    def set_drop_path_rows(self, on):
+        self.drop_path_rows = bool(on)
+        check(lib().uvit_engine_set_drop_path_rows(self.h, 1 if on else 0), "set_drop_path_rows")
 
     def sync_shadows(self, which=3):
         check(lib().uvit_engine_sync_shadows(self.h, which, cur_stream()), "sync_shadows")
