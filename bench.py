@@ -340,6 +340,8 @@ def main():
     if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)
         keep = feed["mask_rows"]
         feed["mask_rows"] = 0
+        keep_dp = engine.drop_path_rows
+        engine.set_drop_path_rows(False)                 # ... and every Block branch on every sample, dropped ones multiplied by 0
         for i in range(2):
             step(a.warmup + a.steps + 10 + i)
         fence(); t1 = time.perf_counter()
@@ -348,6 +350,7 @@ def main():
         fence()
         all_rows_value = round(a.batch * a.steps / (time.perf_counter() - t1), 2)
         feed["mask_rows"] = keep
+        engine.set_drop_path_rows(keep_dp)
     stats = torch.zeros(2).pin_memory()
     check(L.uvit_engine_read_stats(engine.h, C.c_void_p(stats.data_ptr()), cur_stream()), "stats")
     staging = None
@@ -366,8 +369,26 @@ def main():
         # dgrads, two wgrads = 8 GEMMs of 2 rows C Hd) skips the rows that feed neither the loss nor the targets
         M_rows, Cd, Hdd = a.batch * 197, model.embed_dim, 4 * model.embed_dim
         skipped = 16.0 * max(M_rows - feed["mask_rows"], 0) * Cd * Hdd / a.batch / 1e9 if (feed["mask_rows"] and not stochastic) else 0.0
+        # drop-path sample lists (base model): a student branch skips the samples its DropPath dropped -- in expectation rate_l of them in
+        # layer l (rates linspace(0, 0.25, depth)); per token the attention branch is 8 C^2 (QKV, proj) + 4 N C (core), the MLP 16 C^2, and
+        # the student runs them forward + backward (x3; the attention core's backward is 2.5 forwards).  The masked-row last block keeps
+        # the dense attention branch and its own row list.
+        dp_lists = bool(engine.drop_path_rows) and not stochastic
+        skipped_dp = 0.0
+        if dp_lists:
+            depth_ = model.depth
+            for l_ in range(depth_ - 1 if feed["mask_rows"] else depth_):
+                r_ = 0.25 * l_ / (depth_ - 1)
+                skipped_dp += r_ * 197 * (3 * 8 * Cd * Cd + 3.5 * 4 * 197 * Cd + 3 * 16 * Cd * Cd) / 1e9
+        skipped += skipped_dp
         traffic = pmc_traffic()
         rp = rocprof_avg_us()
+
+        # algorithmic bytes of the FULL-SIZE launch of each kind (all rows, all samples): the shape the PMC passes measured (tools/pmc_run.sh runs
+        # --all-rows with UVIT_DP_ROWS=0); the event brackets cover every launch, compact ones included, at their mean row count
+        Mf = float(M_rows * (2 if stochastic else 1))
+        full_bytes = {"fc1_teacher": 2.0 * (Mf * Cd + Hdd * Cd + Mf * Hdd), "fc1_student": 2.0 * (Mf * Cd + Hdd * Cd + 2 * Mf * Hdd),
+                      "proj": 2.0 * (M_rows * Cd + Cd * Cd) + 8.0 * M_rows * Cd, "fc2": 2.0 * (M_rows * Hdd + Cd * Hdd) + 8.0 * M_rows * Cd}
 
         def entry(name, src):
             ms_, n_, fl_, by_ = src[name]
@@ -375,9 +396,11 @@ def main():
                  "frac_mfma": round(fl_ / (ms_ * 1e-3) / PEAK_BF16, 4), "flops_per_launch": fl_, "algorithmic_bytes": int(by_),
                  "frac_hbm_algorithmic": round(by_ / (ms_ * 1e-3) / PEAK_HBM, 4)}
             t = traffic.get(name)
-            if t:
+            if t and name in full_bytes:
                 d["traffic"] = t["fetch"] + t["write"]
-                d["traffic_over_algorithmic"] = round((t["fetch"] + t["write"]) / by_, 3)
+                d["traffic_shape"] = "full-size launch (all rows, all samples)"
+                d["full_size_algorithmic_bytes"] = int(full_bytes[name])
+                d["traffic_over_algorithmic"] = round((t["fetch"] + t["write"]) / full_bytes[name], 3)
                 d["traffic_detail"] = t
             return d
         best = alone if alone else sched              # single-stream numbers are the ones rocprofv3's summary can reproduce
@@ -406,17 +429,22 @@ def main():
                        "final_loss": round(float(stats[0]), 5),
                        "last_block_mlp_rows": (f"{feed['mask_rows']} masked rows of {a.batch * 197} (host-side bound; same results as all rows)"
                                                if feed["mask_rows"] and not stochastic else "all"),
+                       "drop_path_rows": ("each Block branch of the student runs on the samples its DropPath kept (compact rows sized on the host from the "
+                                          f"device's counter-based hash; same results as all samples); expected skip {skipped_dp:.2f} GFLOP/image"
+                                          if dp_lists else "all samples"),
                        "step_mfma_frac_note": "step_mfma_frac = algorithmic FLOPs of the reference's step (SURVEY 8d) / time / peak; executed_flops_frac "
-                                              "counts only the FLOPs this step runs (the last block's MLP skips unmasked rows); value_all_rows = img/s "
-                                              "with every row through that MLP, same process"},
+                                              "counts only the FLOPs this step runs (the last block's MLP skips unmasked rows, every student branch the samples its DropPath "
+                                              "dropped); value_all_rows = img/s with every row and every sample through every branch, same process"},
             "roofline": {"bound": "mfma",
                          "kernel": "gemm_nt256_kernel<EPI_RESID, 320x256 tile> -- the largest kernel by time of the single-stream rocprofv3 summary: "
                                    "the Linears with the LayerScale x DropPath x fp32-residual epilogue (attention proj, K=768, and MLP fc2, K=3072; "
-                                   f"M={M_rows} N={Cd}), {fam_n} timed launches; per-shape figures and the fc1 launches under by_instantiation",
+                                   f"M<={M_rows} N={Cd}), {fam_n} timed launches; per-shape figures and the fc1 launches under by_instantiation",
                          "achieved": round(achieved, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / PEAK_BF16, 4),
                          "avg_launch_ms": round(fam_ms / max(fam_n, 1), 4), "launches_timed": fam_n,
                          "algorithmic_bytes": int(fam_by / max(fam_n, 1)), "traffic": fam_traffic,
+                         "traffic_shape": "full-size launches (all rows, all samples); achieved / avg_launch_ms / algorithmic_bytes are over every launch "
+                                          "of the family, the compact ones (drop-path sample lists, masked-row last block) included",
                          "traffic_source": "profiles/round4_pmc_hbm.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a single-stream run, tools/pmc_run.sh; "
                                            "2 x FETCH_SIZE + WRITE_SIZE per launch, per shape; FETCH_SIZE counts Infinity-Cache hits, dram_read "
                                            "(TCC_EA0_RDREQ_DRAM, where collected) is the part that reached HBM)",

@@ -192,7 +192,8 @@ int uvit_engine_profile(uvit_engine* e, int enable, int max_launches);
 int uvit_engine_profile_read(uvit_engine* e, double* total_ms, int* launches, double* flops_per_launch);
 /* The brackets by kind: 0 = fc1 of the teacher (bias + GELU), 1 = fc1 of the student (also stores GELU'), 2 = attention proj and
  * 3 = fc2 (both: bias, LayerScale, DropPath, fp32 residual epilogue), -1 = kinds 0 and 1 together.  bytes_per_launch (nullable) =
- * the launch's algorithmic HBM bytes (operands read once, results written once). */
+ * the launch's algorithmic HBM bytes (operands read once, results written once).  Every launch of a kind is bracketed, compact ones
+ * included (drop-path sample lists, the masked-row last block): FLOPs and bytes are those of the MEAN row count of the kind's launches. */
 int uvit_engine_profile_read_kind(uvit_engine* e, int kind, double* total_ms, int* launches, double* flops_per_launch,
                                   double* bytes_per_launch);
 /* enqueues the copy of 8 floats {loss, grad_norm, -, -, std_loss0 (the `loss_var0` meter), ...} of the last step into (pinned) host memory behind the step's kernels and returns:

@@ -329,14 +329,30 @@ void droppath_lists_kernel(const float* __restrict__ scales, int* __restrict__ p
     const int lb = blockIdx.x;
     const float* sc = scales + (size_t)lb * B;
     int* p = pos + (size_t)lb * B; int* m = bmap + (size_t)lb * B; int* r = rows + (size_t)lb * rows_stride;
+    // slots by a block-wide prefix count over the keep flags, 256 samples per pass (wave ballots + the four wave totals through LDS)
+    __shared__ int s_w[4];
     __shared__ int s_k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const bool keep = b < B && sc[b] != 0.f;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int before = base;
+        for (int q = 0; q < wave; ++q) before += s_w[q];
+        const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (b < B) p[b] = keep ? slot : -1;
+        if (keep) m[slot] = b;
+        base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    for (int b = base + threadIdx.x; b < B; b += 256) m[b] = 0;
     if (threadIdx.x == 0) {
-        int k = 0;
-        for (int b = 0; b < B; ++b) { if (sc[b] != 0.f) { p[b] = k; m[k] = b; ++k; } else p[b] = -1; }
-        for (int b = k; b < B; ++b) m[b] = 0;
-        cnt[lb] = k * tokens;
-        cnt[gridDim.x + lb] = k != host.k[lb];            // checked by droppath_lists_guard_kernel once the loss has been zeroed
-        s_k = k;
+        cnt[lb] = base * tokens;
+        cnt[gridDim.x + lb] = base != host.k[lb];         // checked by droppath_lists_guard_kernel once the loss has been zeroed
+        s_k = base;
     }
     __syncthreads();
     __threadfence_block();

@@ -154,10 +154,11 @@ struct uvit_engine {
     float *dXa, *dXb;
     bf16 *dY1[2], *dY2[2], *dH[2], *dLN, *dAttn, *dqkv[2];   // [layer parity]: read by the wgrad stream while the next layer runs
     float *dp_scales, *dp_rates;
-    // drop-path sample lists (base model, training step): per (layer, branch) list lb = 2 l + branch
+    // drop-path sample lists (training step): per (layer, draw) list lb = 2 S l + k, k as in dp_ptr (base: attn, mlp; two-stream: mean attn,
+    // mean mlp, cov attn, cov mlp -- only the two MLP lists are used there: the two-stream attention needs both streams of a sample)
     int *dpl_pos = nullptr, *dpl_bmap = nullptr, *dpl_rows = nullptr, *dpl_cnt = nullptr;
     size_t dpl_stride = 0;                 // ints per rows list
-    int dpl_K[2 * UVIT_MAX_DEPTH] = {};    // kept samples per list, from the host's evaluation of the drop-path hash
+    int dpl_K[128] = {};                   // kept samples per list (2 S lists per layer), from the host's evaluation of the drop-path hash
     bool dpl_enable = true;                // uvit_engine_set_drop_path_rows
     bool dpl_on = false;                   // the current step runs with lists
     std::vector<float> dp_rates_host;
@@ -185,6 +186,7 @@ struct uvit_engine {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // pairs
     std::vector<int> prof_kind;        // per pair: UVIT_PROF_* (which Linear of the block the bracket holds)
+    std::vector<int> prof_rows;        // per pair: rows of the bracketed launch (compact launches run fewer than B x tokens)
     size_t prof_used = 0;
     // stacked-row helpers
     size_t rows_all() const { return (size_t)(S - 1) * Mpad + M; }      // rows a stacked row-wise op covers
@@ -239,10 +241,11 @@ static void plan_workspace(uvit_engine* e, Bump& b) {
     }
     e->dLN = b.take<bf16>(Mp * C); e->dAttn = b.take<bf16>(Mp * C);
     e->dp_scales = b.take<float>((size_t)c.depth * 2 * e->S * e->B); e->dp_rates = b.take<float>(c.depth);
-    if (e->S == 1) {
+    if ((size_t)c.depth * 2 * e->S <= 128) {
+        const size_t nl = (size_t)c.depth * 2 * e->S;
         e->dpl_stride = roundup((size_t)e->B * e->N, 64);
-        e->dpl_pos = b.take<int>((size_t)c.depth * 2 * e->B); e->dpl_bmap = b.take<int>((size_t)c.depth * 2 * e->B);
-        e->dpl_rows = b.take<int>((size_t)c.depth * 2 * e->dpl_stride); e->dpl_cnt = b.take<int>((size_t)c.depth * 4 + 64);    // counts, then the host-mismatch flags
+        e->dpl_pos = b.take<int>(nl * e->B); e->dpl_bmap = b.take<int>(nl * e->B);
+        e->dpl_rows = b.take<int>(nl * e->dpl_stride); e->dpl_cnt = b.take<int>(2 * nl + 64);    // counts, then the host-mismatch flags
     }
     e->loss = b.take<float>(64); e->gnorm = e->loss + 1; e->sumsq = (double*)(e->loss + 2);
     e->wl_scratch = b.take<float>(16 + BPp);
@@ -449,6 +452,7 @@ extern "C" int uvit_engine_profile(uvit_engine* e, int enable, int max_launches)
     if (enable && e->prof_ev.empty()) {
         e->prof_ev.resize((size_t)(max_launches > 0 ? max_launches : 4096) * 2);
         e->prof_kind.assign(e->prof_ev.size() / 2, -1);
+        e->prof_rows.assign(e->prof_ev.size() / 2, 0);
         for (auto& ev : e->prof_ev) if (hipEventCreate(&ev) != hipSuccess) return UVIT_ERR_LAUNCH;
     }
     e->prof_on = enable != 0;
@@ -463,17 +467,18 @@ enum { UVIT_PROF_FC1_T = 0, UVIT_PROF_FC1_S = 1, UVIT_PROF_PROJ = 2, UVIT_PROF_F
 extern "C" int uvit_engine_profile_read_kind(uvit_engine* e, int kind, double* total_ms, int* launches, double* flops_per_launch,
                                              double* bytes_per_launch) {
     if (!e || !total_ms || !launches || kind >= UVIT_PROF_KINDS) return UVIT_ERR_ARG;
-    double t = 0.0; int n = 0;
+    double t = 0.0, rows = 0.0; int n = 0;
     for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
         const int k = e->prof_kind[i / 2];
         if (kind < 0 ? (k != UVIT_PROF_FC1_T && k != UVIT_PROF_FC1_S) : k != kind) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) != hipSuccess) return UVIT_ERR_LAUNCH;
-        t += ms; ++n;
+        t += ms; ++n; rows += e->prof_rows[i / 2];
     }
     *total_ms = t; *launches = n;
-    // algorithmic work of ONE launch: rows of one stream for proj / fc2 (a launch per stream), the stacked rows for fc1
-    const double M1 = (double)e->cur_B * e->N, Mall = (double)(e->S - 1) * e->Mpad + M1, C = e->C, Hd = e->Hd;
+    // algorithmic work of ONE launch, at the MEAN row count of the bracketed launches (rows of one stream for proj / fc2, the stacked rows
+    // for fc1; compact launches -- drop-path sample lists, the masked-row last block -- run fewer rows than B x tokens)
+    const double M1 = n ? rows / n : (double)e->cur_B * e->N, Mall = M1, C = e->C, Hd = e->Hd;
     double fl = 0.0, by = 0.0;
     if (kind < 0 || kind == UVIT_PROF_FC1_T || kind == UVIT_PROF_FC1_S) {
         fl = 2.0 * Mall * Hd * C;
@@ -527,16 +532,28 @@ static const float* dp_ptr(uvit_engine* e, bool on, int l, int st, int branch, i
 // stream), the Linears / the attention core run K * tokens rows, the residual epilogue scatters through the row list, and backward mirrors it.
 // The host evaluates the same integer hash as droppath_kernel to size the launches; the lists themselves are built on the device.
 struct DpList { const int *pos, *bmap, *rows, *cnt; int K; };
-static bool dp_list(const uvit_engine* e, int l, int branch, DpList& d) {
-    if (!e->dpl_on) return false;
-    const int lb = 2 * l + branch, K = e->dpl_K[lb];
-    if (K <= 0 || K >= e->B) return false;               // nobody dropped: the dense launches; everybody dropped: dense too (0 * branch)
+static void dp_list_get(const uvit_engine* e, int l, int st, int branch, DpList& d) {
+    const int lb = 2 * e->S * l + (e->S == 2 ? 2 * st + branch : branch);
     d.pos = e->dpl_pos + (size_t)lb * e->B; d.bmap = e->dpl_bmap + (size_t)lb * e->B;
-    d.rows = e->dpl_rows + (size_t)lb * e->dpl_stride; d.cnt = e->dpl_cnt + lb; d.K = K;
-    return true;
+    d.rows = e->dpl_rows + (size_t)lb * e->dpl_stride; d.cnt = e->dpl_cnt + lb; d.K = e->dpl_K[lb];
+}
+// base model: the list of (layer, branch) when it drops somebody (nobody dropped: the dense launches; everybody dropped: dense too, 0 * branch)
+static bool dp_list(const uvit_engine* e, int l, int branch, DpList& d) {
+    if (!e->dpl_on || e->S != 1) return false;
+    dp_list_get(e, l, 0, branch, d);
+    return d.K > 0 && d.K < e->B;
+}
+// two-stream model: the MLP branch of a layer runs compact when either stream dropped somebody and neither dropped everybody; the kept rows of
+// the mean stream, then those of the covariance stream, are stacked without a gap (fc1 / fc2 share their weights between the streams)
+static bool dp_list2(const uvit_engine* e, int l, DpList (&d)[2]) {
+    if (!e->dpl_on || e->S != 2) return false;
+    dp_list_get(e, l, 0, 1, d[0]); dp_list_get(e, l, 1, 1, d[1]);
+    return d[0].K > 0 && d[1].K > 0 && (d[0].K < e->B || d[1].K < e->B);
 }
 static int dp_lists_begin(uvit_engine* e, uint32_t seed, uint32_t it, int Bc, hipStream_t s) {
-    const int depth = e->cfg.depth, nbr = 2;
+    const int depth = e->cfg.depth, nbr = 2 * e->S;
+    e->dpl_on = false;
+    if (!e->dpl_pos) return UVIT_OK;
     bool any = false;
     for (int l = 0; l < depth; ++l)
         for (int br = 0; br < nbr; ++br) {
@@ -549,7 +566,7 @@ static int dp_lists_begin(uvit_engine* e, uint32_t seed, uint32_t it, int Bc, hi
                 for (int b = 0; b < Bc; ++b) K += uvit_hash32((uint32_t)b ^ key) >= thr ? 1 : 0;
             }
             e->dpl_K[nbr * l + br] = K;
-            any = any || (K > 0 && K < Bc);
+            any = any || (K > 0 && K < Bc && (e->S == 1 || (br & 1)));
         }
     e->dpl_on = any;
     if (!any) return UVIT_OK;
@@ -572,7 +589,7 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     unsigned* const tcnt = (e->tile_cnt && dyn_tiles) ? e->tile_cnt + ((e->dual && s == e->aux) ? 16 : 0) : nullptr;
     // drop-path sample lists of the two branches (S == 1, not the masked-row last block): Ma / Mm rows instead of M
     DpList da{}, dm{};
-    const bool la = lists && R == 0 && S == 1 && Bc == e->B && dp_list(e, l, 0, da);
+    const bool la = lists && S == 1 && Bc == e->B && dp_list(e, l, 0, da);     // (also in the masked-row last block: only its MLP keeps the row list)
     const bool lm = lists && R == 0 && S == 1 && Bc == e->B && dp_list(e, l, 1, dm);
     const int Ma = la ? da.K * e->N : M;
     if (la) CHECK(uvit_ln_fwd_keep_launch(x_in, da.pos, w.f + o.n1w, w.f + o.n1b, a.ln1, a.mean1, a.rstd1, x_mid, M, C, e->N, e->cfg.ln_eps, s));
@@ -590,9 +607,9 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
                                     pdrop, seed, (uint32_t)l, s));
     }
     // optional HIP-event brackets around the block's full-size forward Linears (bench.py's roofline block)
-    auto prof_begin = [&](int kind) -> bool {
+    auto prof_begin = [&](int kind, int rows) -> bool {
         if (!(e->prof_on && e->prof_used + 2 <= e->prof_ev.size())) return false;
-        e->prof_kind[e->prof_used / 2] = kind;
+        e->prof_kind[e->prof_used / 2] = kind; e->prof_rows[e->prof_used / 2] = rows;
         (void)hipEventRecord(e->prof_ev[e->prof_used], s);
         return true;
     };
@@ -601,16 +618,24 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         GemmEpi p; p.out = x_mid + st * Mp * C; p.out2 = save ? a.projout + st * Mp * C : nullptr; p.bias = w.f + off_projb(o, st);
         p.gamma = w.f + o.g1; p.resid = x_in + st * Mp * C; p.rowscale = dp_ptr(e, dp_on, l, st, 0, Bc); p.ldo = C; p.tokens = e->N;
         if (la) { p.rowmap = da.rows; p.rowcount = da.cnt; }
-        const bool pp = !la && prof_begin(UVIT_PROF_PROJ);
+        const bool pp = prof_begin(UVIT_PROF_PROJ, Ma);
         CHECK(GEMM_NT(EPI_RESID, a.attn + st * Mp * C, w.b + off_projw(o, st), Ma, C, C, C, C, &p, s));
         prof_end(pp);
     }
-    const int Mm = lm ? dm.K * e->N : (R > 0 ? R : Mall);
+    DpList d2[2] = {};
+    const bool lm2 = lists && S == 2 && Bc == e->B && dp_list2(e, l, d2);
+    const size_t off2[2] = {0, lm2 ? (size_t)d2[0].K * e->N : Mp};       // first compact row of each stream's MLP rows
+    const int Mm = lm ? dm.K * e->N : (lm2 ? (d2[0].K + d2[1].K) * e->N : (R > 0 ? R : Mall));
+    if (lm2) {
+        for (int st = 0; st < 2; ++st)
+            CHECK(uvit_ln_fwd_keep_launch(x_mid + st * Mp * C, d2[st].pos, w.f + o.n2w, w.f + o.n2b, a.ln2 + off2[st] * C, a.mean2 + off2[st],
+                                          a.rstd2 + off2[st], x_out + st * Mp * C, M, C, e->N, e->cfg.ln_eps, s));
+    } else
     if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
     else if (lm) CHECK(uvit_ln_fwd_keep_launch(x_mid, dm.pos, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, x_out, M, C, e->N, e->cfg.ln_eps, s));
     else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd; f1.tile_counter = tcnt;
-    const bool prof = R == 0 && !lm && prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T);    // (only full-size launches are timed)
+    const bool prof = prof_begin(save ? UVIT_PROF_FC1_S : UVIT_PROF_FC1_T, Mm);
     // student (save): a.h receives gelu'(h) -- all that backward needs of h -- computed beside gelu(h)
     CHECK(GEMM_NT(save ? EPI_GELU_DG : EPI_GELU, a.ln2, w.b + o.fc1w, Mm, Hd, C, C, C, &f1, s));
     prof_end(prof);
@@ -619,8 +644,10 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         f2.gamma = w.f + o.g2; f2.resid = x_mid + st * Mp * C; f2.rowscale = dp_ptr(e, dp_on, l, st, 1, Bc); f2.ldo = C; f2.tokens = e->N;
         if (R > 0) { f2.rowmap = e->rowidx; f2.rowcount = e->count; }
         else if (lm) { f2.rowmap = dm.rows; f2.rowcount = dm.cnt; }
-        const bool pf2 = R == 0 && !lm && prof_begin(UVIT_PROF_FC2);
-        CHECK(GEMM_NT(EPI_RESID, a.a + st * Mp * Hd, w.b + o.fc2w, R > 0 ? R : (lm ? Mm : M), C, Hd, Hd, Hd, &f2, s));
+        else if (lm2) { f2.rowmap = d2[st].rows; f2.rowcount = d2[st].cnt; }
+        const int M2 = R > 0 ? R : (lm ? Mm : (lm2 ? d2[st].K * e->N : M));
+        const bool pf2 = prof_begin(UVIT_PROF_FC2, M2);
+        CHECK(GEMM_NT(EPI_RESID, a.a + (lm2 ? off2[st] : st * Mp) * Hd, w.b + o.fc2w, M2, C, Hd, Hd, Hd, &f2, s));
         prof_end(pf2);
     }
     return UVIT_OK;
@@ -655,7 +682,7 @@ static int run_forward(uvit_engine* e, int which, const float* images, const int
     if (dp_on) CHECK(uvit_droppath_launch(e->dp_scales, e->dp_rates, e->cfg.depth, 2 * e->S, Bc, seed, it, s));
     if (!teacher) {
         e->dpl_on = false;
-        if (dp_on && save_student && e->dpl_enable && e->S == 1 && Bc == e->B) CHECK(dp_lists_begin(e, seed, it, Bc, s));
+        if (dp_on && save_student && e->dpl_enable && Bc == e->B) CHECK(dp_lists_begin(e, seed, it, Bc, s));
     }
     const uint32_t aseed = uvit_hash32(seed ^ (it * 0x85EBCA6Bu + 0x1234567u));
     if (!teacher) { e->last_dropout = dropout; e->last_seed = aseed; e->last_it = it; }
@@ -834,7 +861,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
         CHECK(uvit_variance_loss_launch(e->outputs[0], e->count, hp->var_w0, hp->var_margin0, ls, e->var_scratch, e->loss, e->loss + 4,
                                         e->dout[0], BP, C, s));
     if (e->compact_R > 0) CHECK(uvit_rows_guard_launch(e->count, e->compact_R, e->loss, s));     // more masked rows than the host promised
-    if (e->dpl_on) CHECK(uvit_droppath_lists_guard_launch(e->dpl_cnt, 2 * e->cfg.depth, e->loss, s));   // a sample list that is not the host's
+    if (e->dpl_on) CHECK(uvit_droppath_lists_guard_launch(e->dpl_cnt, 2 * e->S * e->cfg.depth, e->loss, s));   // a sample list that is not the host's
     if (e->S == 2)
         CHECK(uvit_wasserstein_loss_launch(e->outputs[0], e->outputs[1], e->targets[0], e->targets[1], e->count, hp->lambda_pretraining,
                                            ls, e->wl_scratch, e->loss, e->dout[0], e->dout[1], BP, C, s));
@@ -890,11 +917,16 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     // drop-path sample lists (see forward_layer): the attention branch on Ma = Ka tokens rows, the MLP branch on Km tokens rows; the wgrad
     // reductions run to the next multiple of 64 (pad rows of the dY operands are zero)
     DpList da{}, dm{}, dm1{};
-    const bool la = R == 0 && S == 1 && dp_list(e, l, 0, da);
+    const bool la = S == 1 && dp_list(e, l, 0, da);
     const bool lm = R == 0 && S == 1 && dp_list(e, l, 1, dm);
     const bool lm1 = l > 0 && S == 1 && dp_list(e, l - 1, 1, dm1);          // the MLP branch of the layer below (its LayerScale backward rides here)
     const int Ma = la ? da.K * e->N : M, Mac = la ? (int)roundup(Ma, 64) : Mred1;
-    const int Mmlp = R > 0 ? R : (lm ? (int)roundup((size_t)dm.K * e->N, 64) : Mall), Mmlp_red = (R > 0 || lm) ? Mmlp : Mred;
+    // two-stream model: the MLP branch on the kept rows of both streams, stacked without a gap (see forward_layer)
+    DpList dl2[2] = {}, dl21[2] = {};
+    const bool lm2 = dp_list2(e, l, dl2), lm21 = l > 0 && dp_list2(e, l - 1, dl21);
+    const size_t off2[2] = {0, lm2 ? (size_t)dl2[0].K * e->N : Mp}, off21[2] = {0, lm21 ? (size_t)dl21[0].K * e->N : Mp};
+    const int Mmlp = R > 0 ? R : (lm ? (int)roundup((size_t)dm.K * e->N, 64) : (lm2 ? (int)roundup((size_t)(dl2[0].K + dl2[1].K) * e->N, 64) : Mall));
+    const int Mmlp_red = (R > 0 || lm || lm2) ? Mmlp : Mred;
     // weight gradients: one grouped launch per layer (bias column sums of fc1 / q / v fused) when every Linear has
     // 256-multiple dimensions; otherwise one launch per Linear as the operands become available
     TnProb wg[UVIT_TN_GROUP_MAX];
@@ -921,6 +953,11 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     if (R > 0)       // compact dY1 from the residual-stream gradient and the saved branch output at the listed rows (S == 1)
         CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), R, C, e->N, NREP,
                                  e->n_nd, s, e->rowidx, e->count));
+    else if (e->ls_prefused != l && lm2)   // two-stream: compact dY1 of each stream's kept samples, stacked; the second launch zero-fills the pad rows
+        for (int st = 0; st < 2; ++st)
+            CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + off2[st] * C,
+                                     RP(o.g2), RP(o.fc2b), st == 0 ? dl2[0].K * e->N : Mmlp - dl2[0].K * e->N, C, e->N, NREP, e->n_nd, s,
+                                     dl2[st].rows, dl2[st].cnt));
     else if (e->ls_prefused != l && lm)    // compact dY1 of the kept samples (pad rows zero)
         CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), Mmlp, C, e->N, NREP,
                                  e->n_nd, s, dm.rows, dm.cnt));
@@ -943,7 +980,15 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     GemmEpi d2; d2.out = e->dLN; d2.ldo = C;
     CHECK(GEMM_NT(EPI_BF16, dH, wt + o.fc1w, Mmlp, C, Hd, Hd, Hd, &d2, s));
     // --- attention branch: x_mid = x_in + dp * gamma1 * proj(attn(ln1(x_in)))   (proj differs per stream)
-    if (la || lm) {
+    if (lm2) {
+        // two-stream: LayerNorm 2 backward through each stream's MLP list; the attention branch's LayerScale backward stays dense
+        for (int st = 0; st < 2; ++st) {
+            const size_t ro = st * Mp, eo = ro * C;
+            CHECK(uvit_ln_bwd_keep_launch(e->dLN + off2[st] * C, e->XM[l] + eo, dl2[st].pos, a.mean2 + off2[st], a.rstd2 + off2[st], pf + o.n2w,
+                                          e->dXa + eo, e->dXb + eo, RP(o.n2w), RP(o.n2b), a.projout + eo, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B),
+                                          dY2 + eo, RP(o.g1), RP(off_projb(o, st)), nullptr, nullptr, e->N, M, C, NREP, e->n_nd, s));
+        }
+    } else if (R == 0 && (la || lm)) {
         // LayerNorm 2 backward (MLP list) + the attention branch's LayerScale backward (attention list) over the dense rows
         CHECK(uvit_ln_bwd_keep_launch(e->dLN, e->XM[l], lm ? dm.pos : nullptr, a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b),
                                       a.projout, pf + o.g1, dp_ptr(e, dp_on, l, 0, 0, e->B), dY2, RP(o.g1), RP(off_projb(o, 0)),
@@ -954,7 +999,8 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
             CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->XM[l] + eo, a.mean2 + ro, a.rstd2 + ro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
                                         RP(o.n2w), RP(o.n2b), a.projout + eo, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + eo,
                                         RP(o.g1), RP(off_projb(o, st)), e->N, R > 0 ? R : M, C, NREP, e->n_nd, s,
-                                        R > 0 ? e->rowidx : nullptr, R > 0 ? e->count : nullptr));
+                                        R > 0 ? e->rowidx : nullptr, R > 0 ? e->count : nullptr,
+                                        (R > 0 && la) ? da.pos : nullptr));      // masked-row last block: dY2 compact by the attention list (rest pre-zeroed)
         }
     } else {
         CHECK(uvit_ln_bwd_launch(e->dLN, e->XM[l], a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b), Mall, C, NREP, e->n_nd, s));
@@ -1003,7 +1049,19 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     if (e->dual) HIPCHECK(hipEventRecord(e->ev_wdone[l], ws));
     GemmEpi d4; d4.out = e->dLN; d4.ldo = C;
     CHECK(GEMM_NT(EPI_BF16, dqkv, wt + o.qkvw, la ? Ma : Mall, C, 3 * C, 3 * C, 3 * C, &d4, s));
-    if (la || lm1) {
+    if (lm21) {
+        // two-stream: LayerNorm 1 backward (dense) + the LayerScale backward of layer l-1's MLP branch into its stacked compact dY1
+        if (e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
+        const LayerOff& on = e->lo.L[l - 1];
+        for (int st = 0; st < 2; ++st) {
+            const size_t ro = st * Mp, eo = ro * C;
+            CHECK(uvit_ln_bwd_keep_launch(e->dLN + eo, e->X[l] + eo, nullptr, a.mean1 + ro, a.rstd1 + ro, pf + o.n1w, e->dXb + eo, e->dXa + eo,
+                                          RP(o.n1w), RP(o.n1b), e->acts[l - 1].mlpout + eo, pf + on.g2, dp_ptr(e, dp_on, l - 1, st, 1, e->B),
+                                          e->dY1[(l - 1) & 1] + off21[st] * C, RP(on.g2), RP(on.fc2b), dl21[st].pos, st == 1 ? dl21[1].cnt : nullptr,
+                                          e->N, M, C, NREP, e->n_nd, s, st == 1 ? dl21[0].K * e->N : 0));
+        }
+        e->ls_prefused = l - 1;
+    } else if (la || lm1) {
         // LayerNorm 1 backward (attention list) + the LayerScale backward of layer l-1's MLP branch (its list), dense rows
         if (l > 0 && e->dual && l + 1 < e->cfg.depth) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[l + 1], 0));
         const LayerOff& on = e->lo.L[l > 0 ? l - 1 : 0];

@@ -94,6 +94,7 @@ void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ rowidx, 
 //     (MI355X_MICROARCH.md, Global float atomics), and they were a large part of this kernel's 108 us.
 struct LsNext {
     const bf16* y; const float* gamma; const float* rowscale; bf16* dy; float* dgamma; float* dbias; int tokens;
+    const int* pos = nullptr;      // row-list kernel only: dy is COMPACT by this sample map (drop-path sample list of the branch), -1 = dropped
 };
 #define LNB_WAVES 8
 
@@ -102,7 +103,7 @@ struct LnbRow {                      // operands of one row, as loaded
     float4 x[NV], dres[NV];
     bf16x4 dy[NV], y[LS ? NV : 1];
     float mean, rstd, dp;
-    int xr;
+    int xr, yr;                      // residual-stream row; row of dy_next (-1: its branch dropped the sample)
 };
 
 template <int NV, bool LS>
@@ -112,8 +113,11 @@ __device__ __forceinline__ void lnb_load(LnbRow<NV, LS>& r, int row, const bf16*
     const int xr = rowidx ? rowidx[row] : row;
     r.xr = xr;
     r.mean = mean_i[row]; r.rstd = rstd_i[row];
-    r.dp = 1.0f;
-    if constexpr (LS) { if (ls.rowscale) r.dp = ls.rowscale[xr / ls.tokens]; }
+    r.dp = 1.0f; r.yr = xr;
+    if constexpr (LS) {
+        if (ls.rowscale) r.dp = ls.rowscale[xr / ls.tokens];
+        if (ls.pos) { const int smp = xr / ls.tokens, sl = ls.pos[smp]; r.yr = sl < 0 ? -1 : sl * ls.tokens + (xr - smp * ls.tokens); }
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
@@ -184,12 +188,12 @@ void ln_bwd_kernel(const bf16* __restrict__ dy, const float* __restrict__ x, con
                 const float4 o = make_float4(cur.dres[k].x + rstd * (g[k].x - s1 - h[k].x * s2), cur.dres[k].y + rstd * (g[k].y - s1 - h[k].y * s2),
                                              cur.dres[k].z + rstd * (g[k].z - s1 - h[k].z * s2), cur.dres[k].w + rstd * (g[k].w - s1 - h[k].w * s2));
                 ((float4*)(dx + (size_t)cur.xr * C))[i] = o;
-                if constexpr (LS) {
+                if constexpr (LS) if (cur.yr >= 0) {
                     const float e0 = o.x * cur.dp, e1 = o.y * cur.dp, e2 = o.z * cur.dp, e3 = o.w * cur.dp;
                     ag.v[k].x += e0 * bf2f(cur.y[k][0]); ag.v[k].y += e1 * bf2f(cur.y[k][1]);
                     ag.v[k].z += e2 * bf2f(cur.y[k][2]); ag.v[k].w += e3 * bf2f(cur.y[k][3]);
                     const bf16x4 ob = {f2bf(e0 * gm[k].x), f2bf(e1 * gm[k].y), f2bf(e2 * gm[k].z), f2bf(e3 * gm[k].w)};
-                    ((bf16x4*)(ls.dy + (size_t)cur.xr * C))[i] = ob;
+                    ((bf16x4*)(ls.dy + (size_t)cur.yr * C))[i] = ob;
                     ay.v[k].x += bf2f(ob[0]); ay.v[k].y += bf2f(ob[1]); ay.v[k].z += bf2f(ob[2]); ay.v[k].w += bf2f(ob[3]);
                 }
             }
@@ -264,7 +268,8 @@ void ln_fwd_keep_kernel(const float* __restrict__ x, const int* __restrict__ pos
 // nullptr = every sample kept, dense): a dropped sample's row passes dres through (dx = dres) and adds nothing to dw / db.  posB maps it
 // to the slot of the branch whose LayerScale backward rides along (dy_next compact, y_next dense-indexed; nullptr = dense; ls.dy ==
 // nullptr: no such branch): a dropped sample writes nothing and adds nothing to dgamma / dbias.  The pad rows of dy_next (cntB .. next
-// multiple of 64: the wgrad's reduction length) are zero-filled by the last workgroup.
+// multiple of 64 of pad_base + cntB: the wgrad's reduction length; pad_base = rows in front of dy_next in a stacked buffer) are zero-filled
+// by the last workgroup when cntB is given.
 template <int NV>
 struct LnkRow {
     float4 x[NV], dres[NV];
@@ -304,12 +309,12 @@ void ln_bwd_keep_kernel(const bf16* __restrict__ dy, const float* __restrict__ x
                         const int* __restrict__ posB, const int* __restrict__ cntB, const float* __restrict__ mean_i,
                         const float* __restrict__ rstd_i, const float* __restrict__ w, const float* __restrict__ dres,
                         float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep,
-                        size_t rep_stride, LsNext ls, int rows_per_block) {
+                        size_t rep_stride, LsNext ls, int rows_per_block, int pad_base) {
     __shared__ float red[LNB_WAVES][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
-    if (ls.dy && posB && blockIdx.x == gridDim.x - 1) {
-        const int n = *cntB, npad = (n + 63) & ~63;
+    if (ls.dy && cntB && blockIdx.x == gridDim.x - 1) {
+        const int n = *cntB, npad = ((pad_base + n + 63) & ~63) - pad_base;
         for (int r = n + wave; r < npad; r += LNB_WAVES)
 #pragma unroll
             for (int k = 0; k < NV; ++k)
@@ -515,9 +520,9 @@ int uvit_ln_bwd_launch(const void* dy, const float* x, const float* mean, const 
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                           const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
-                          int M, int C, int nrep, size_t rep_stride, hipStream_t s, const int* rowidx, const int* count) {
+                          int M, int C, int nrep, size_t rep_stride, hipStream_t s, const int* rowidx, const int* count, const int* pos_next) {
     if (ln_shape_ok(M, C) || tokens <= 0 || (rowidx && !count)) return UVIT_ERR_SHAPE;
-    const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
+    const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens, pos_next};
     const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH2(ln_bwd_kernel, true, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x,
                        rowidx, count, mean, rstd, w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
@@ -533,12 +538,12 @@ int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, cons
 int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
                             const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                             const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
-                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s) {
-    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !dres || (posB && (!cntB || !dy_next))) return UVIT_ERR_SHAPE;
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base) {
+    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !dres || ((posB || cntB) && !dy_next) || pad_base < 0) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
     const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH(ln_bwd_keep_kernel, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x, posA, posB, cntB, mean, rstd,
-                       w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb);
+                       w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb, pad_base);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,

@@ -109,13 +109,14 @@ int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, cons
 int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
                             const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                             const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
-                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s);
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base = 0);
 // LayerNorm backward fused with the LayerScale + DropPath backward of the branch that consumes dx next
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                           const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, int tokens,
                           int M, int C, int nrep, size_t rep_stride, hipStream_t s,
-                          const int* rowidx = nullptr, const int* count = nullptr);   // row list: dy / mean / rstd are compact, everything else lives at rowidx[row]
+                          const int* rowidx = nullptr, const int* count = nullptr,    // row list: dy / mean / rstd are compact, everything else lives at rowidx[row]
+                          const int* pos_next = nullptr);                              // (row list only) dy_next compact by this sample map
 int uvit_ln_bwd_scatter_launch(const void* dy_bf16, const float* x, const int* rowidx, const int* count,
                                const float* mean, const float* rstd, const float* w, float* dx, float* dw, float* db,
                                int Mmax, int C, int nrep, size_t rep_stride, hipStream_t s);
