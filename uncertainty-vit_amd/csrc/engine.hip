@@ -992,7 +992,8 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         // LayerNorm 2 backward (MLP list) + the attention branch's LayerScale backward (attention list) over the dense rows
         CHECK(uvit_ln_bwd_keep_launch(e->dLN, e->XM[l], lm ? dm.pos : nullptr, a.mean2, a.rstd2, pf + o.n2w, e->dXa, e->dXb, RP(o.n2w), RP(o.n2b),
                                       a.projout, pf + o.g1, dp_ptr(e, dp_on, l, 0, 0, e->B), dY2, RP(o.g1), RP(off_projb(o, 0)),
-                                      la ? da.pos : nullptr, la ? da.cnt : nullptr, e->N, M, C, NREP, e->n_nd, s));
+                                      la ? da.pos : nullptr, la ? da.cnt : nullptr, e->N, M, C, NREP, e->n_nd, s, 0,
+                                      la ? dqkv : nullptr, 3 * C));      // (also zero-fills the pad rows of dqkv: the attention backward writes Ka samples)
     } else if (fuse_ls) {
         for (int st = 0; st < S; ++st) {
             const size_t ro = st * Mp, eo = ro * C;
@@ -1022,8 +1023,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
         // of layer l was last read by the reduction of layer l + 2, which precedes ev_wdone[l + 2] on that stream (waited for above).
         void* dsw = slabs ? e->ds_ws[par] : nullptr;
         if (S == 1) {
-            // (a compact launch writes Ka samples: the rows up to the wgrad's reduction length are zero-filled here)
-            if (la && Mac > Ma) CHECK(uvit_zero_launch(dqkv + (size_t)Ma * 3 * C, (size_t)(Mac - Ma) * 3 * C * sizeof(bf16), s));
+            // (a compact launch writes Ka samples: the rows up to the wgrad's reduction length are zero-filled by the LayerNorm 2 backward above,
+            //  or here in the masked-row last block, whose LayerNorm 2 backward is the row-list kernel)
+            if (la && R > 0 && Mac > Ma) CHECK(uvit_zero_launch(dqkv + (size_t)Ma * 3 * C, (size_t)(Mac - Ma) * 3 * C * sizeof(bf16), s));
             CHECK(uvit_attn_bwd_fused_launch(a.qkv, a.attn, e->dAttn, biasP, a.lse, e->delta, dqkv, dsw, dsw != nullptr, la ? da.K : e->B, e->H,
                                              e->N, e->NP, 0.125f, pdrop, e->last_seed, (uint32_t)l, s, la ? da.bmap : nullptr));
         } else {

@@ -309,16 +309,19 @@ void ln_bwd_keep_kernel(const bf16* __restrict__ dy, const float* __restrict__ x
                         const int* __restrict__ posB, const int* __restrict__ cntB, const float* __restrict__ mean_i,
                         const float* __restrict__ rstd_i, const float* __restrict__ w, const float* __restrict__ dres,
                         float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int C, int nrep,
-                        size_t rep_stride, LsNext ls, int rows_per_block, int pad_base) {
+                        size_t rep_stride, LsNext ls, int rows_per_block, int pad_base, bf16* __restrict__ pad2, int pad2_cols) {
     __shared__ float red[LNB_WAVES][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = C >> 2;
     if (ls.dy && cntB && blockIdx.x == gridDim.x - 1) {
         const int n = *cntB, npad = ((pad_base + n + 63) & ~63) - pad_base;
-        for (int r = n + wave; r < npad; r += LNB_WAVES)
+        for (int r = n + wave; r < npad; r += LNB_WAVES) {
 #pragma unroll
             for (int k = 0; k < NV; ++k)
                 if (lane + 64 * k < nv) ((bf16x4*)(ls.dy + (size_t)r * C))[lane + 64 * k] = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+            // a second buffer with the same row list (the attention branch's dqkv, written by the attention backward for the kept samples only)
+            if (pad2) for (int c = lane * 4; c < pad2_cols; c += 256) *(bf16x4*)(pad2 + (size_t)r * pad2_cols + c) = bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+        }
     }
     float4 ww[NV], gm[NV];
     RowVec<NV> aw, ab, ag, ay;
@@ -538,12 +541,14 @@ int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, cons
 int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
                             const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                             const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
-                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base) {
-    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !dres || ((posB || cntB) && !dy_next) || pad_base < 0) return UVIT_ERR_SHAPE;
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base,
+                            void* pad2, int pad2_cols) {
+    if (ln_shape_ok(M, C) || tokens <= 0 || (M % tokens) || !dres || ((posB || cntB) && !dy_next) || pad_base < 0 ||
+        (pad2 && (!cntB || pad2_cols <= 0 || (pad2_cols % 4)))) return UVIT_ERR_SHAPE;
     const LsNext ls{(const bf16*)y_next, gamma_next, rowscale_next, (bf16*)dy_next, dgamma_next, dbias_next, tokens};
     const int rpb = lnb_rows(M, LNB_BLOCKS_PER_CU);
     LN_DISPATCH(ln_bwd_keep_kernel, C, dim3((M + rpb - 1) / rpb), dim3(LNB_WAVES * 64), 0, s, (const bf16*)dy, x, posA, posB, cntB, mean, rstd,
-                       w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb, pad_base);
+                       w, dres, dx, dw, db, M, C, nrep > 0 ? nrep : 1, rep_stride, ls, rpb, pad_base, (bf16*)pad2, pad2_cols);
     return uvit_check_launch();
 }
 int uvit_ln_bwd_scatter_launch(const void* dy, const float* x, const int* rowidx, const int* count, const float* mean,

@@ -109,7 +109,8 @@ int uvit_ln_fwd_keep_launch(const float* x, const int* pos, const float* w, cons
 int uvit_ln_bwd_keep_launch(const void* dy, const float* x, const int* posA, const float* mean, const float* rstd, const float* w,
                             const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
                             const float* rowscale_next, void* dy_next, float* dgamma_next, float* dbias_next, const int* posB,
-                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base = 0);
+                            const int* cntB, int tokens, int M, int C, int nrep, size_t rep_stride, hipStream_t s, int pad_base = 0,
+                            void* pad2 = nullptr, int pad2_cols = 0);     // pad2: a second bf16 buffer [rows][pad2_cols] whose pad rows (same range) are zero-filled
 // LayerNorm backward fused with the LayerScale + DropPath backward of the branch that consumes dx next
 int uvit_ln_bwd_ls_launch(const void* dy, const float* x, const float* mean, const float* rstd, const float* w,
                           const float* dres, float* dx, float* dw, float* db, const void* y_next, const float* gamma_next,
