@@ -63,7 +63,8 @@ if __name__ == "__main__":
                 rows.append(f"tile {sq}: top-of-loop gap {r[1] - prev_end:6d}  K loop {r[2] - r[1]:6d}  landed-wait {(r[4] - r[2]) if r[4] > r[2] else -1:6d}  epilogue {r[3] - max(r[4], r[2]):6d}")
             print(f"  workgroup {wg}: " + " | ".join(rows))
         sys.exit(0)
-    ntiles = ((M + 255) // 256) * (N // 256)
+    bm = 320 if variant % 100 == 5 else 256
+    ntiles = ((M + bm - 1) // bm) * (N // 256)
     t = t[:ntiles]
     hw, xcc = t[:, 6], t[:, 7] & 0xF
     cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)      # cu_id, sh_id, se_id, xcc
@@ -84,6 +85,7 @@ if __name__ == "__main__":
         busy.append(sum(b - a for a, b in v))
         last.append(v[-1][1])
     gaps = np.array(gaps)
-    print(f"gap between a tile's end and the next tile's entry on the same CU: mean {gaps.mean():.0f}  p10 {np.percentile(gaps, 10):.0f}  p90 {np.percentile(gaps, 90):.0f} cycles")
+    if len(gaps):
+        print(f"gap between a tile's end and the next tile's entry on the same CU: mean {gaps.mean():.0f}  p10 {np.percentile(gaps, 10):.0f}  p90 {np.percentile(gaps, 90):.0f} cycles")
     print(f"launch span (first entry -> last end) {max(last)} cycles; per-CU busy mean {np.mean(busy):.0f}; tiles per CU min {min(len(v) for v in by.values())} max {max(len(v) for v in by.values())}")
     print(f"first entries: p50 {np.percentile([v[0][0] for v in by.values()], 50):.0f}  max {max(v[0][0] for v in by.values())};  last ends: min {min(last)}  p50 {np.percentile(last, 50):.0f}")
