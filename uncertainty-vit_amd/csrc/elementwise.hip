@@ -30,26 +30,38 @@ __global__ void im2col_kernel(const float* __restrict__ img, bf16* __restrict__ 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024)
 void mask_compact_kernel(const int64_t* __restrict__ mask, int* __restrict__ rowidx, int* __restrict__ count, int B, int P) {
-    __shared__ int part[1024];
-    const int n = B * P, tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
-    int c = 0;
-    for (int i = lo; i < hi; ++i) c += mask[i] != 0;
-    part[tid] = c;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {     // inclusive Hillis-Steele scan
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // (round 4: was one strided scan per thread + a 10-step LDS scan, 95 us at the head of every step)  The flags of up to 32 chunks of 1024
+    // consecutive elements are fetched first, coalesced and all in flight (bit k of a thread = element 1024 k + tid); each chunk is then placed by a
+    // wave ballot plus the 16 wave totals through LDS -- the list stays in element order.
+    __shared__ int s_w[16];
+    const int n = B * P, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int sc = 0; sc < n; sc += 32 * 1024) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int i = sc + k * 1024 + tid;
+            if (i < n && mask[i] != 0) bits |= 1u << k;
+        }
+        for (int k = 0; k < 32 && sc + k * 1024 < n; ++k) {
+            const bool keep = (bits >> k) & 1u;
+            const unsigned long long bal = __ballot(keep);
+            if (lane == 0) s_w[wave] = __popcll(bal);
+            __syncthreads();
+            int before = base, tot = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const int v = s_w[q]; tot += v; if (q < wave) before += v; }
+            if (keep) {
+                const int i = sc + k * 1024 + tid, b = i / P;
+                rowidx[before + __popcll(bal & ((1ull << lane) - 1ull))] = b * (P + 1) + 1 + (i - b * P);
+            }
+            base += tot;
+            __syncthreads();
+        }
     }
-    int pos = part[tid] - c;
-    for (int i = lo; i < hi; ++i)
-        if (mask[i] != 0) { const int b = i / P; rowidx[pos++] = b * (P + 1) + 1 + (i - b * P); }
-    if (tid == 1023) *count = part[1023];
+    if (tid == 0) *count = base;
     // unused tail entries point at a valid row so gathers stay in bounds
-    for (int i = part[1023] + tid; i < n; i += 1024) rowidx[i] = 0;
+    for (int i = base + tid; i < n; i += 1024) rowidx[i] = 0;
 }
 
 __global__ void set_cls_kernel(float* __restrict__ x, const float* __restrict__ cls, int B, int N, int C) {
@@ -97,7 +109,7 @@ __global__ void relpos_scatter_kernel(const float* __restrict__ slab, int nslab,
 #define CP_MAXV 8
 #define CP_ROWS 32
 
-template <int NV>
+template <int NV, int WAVES = 4>
 __device__ __forceinline__ void block_col_atomic(float4 (&acc)[NV], float* out, int nv, float (*red)[64 * 4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -109,7 +121,7 @@ __device__ __forceinline__ void block_col_atomic(float4 (&acc)[NV], float* out, 
             if (wave == 0) {
                 float4 s = ((float4*)red[0])[lane];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) { const float4 a = ((float4*)red[q])[lane]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+                for (int q = 1; q < WAVES; ++q) { const float4 a = ((float4*)red[q])[lane]; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
                 const int i = lane + 64 * k;
                 if (i < nv) { atomicAdd(out + 4 * i, s.x); atomicAdd(out + 4 * i + 1, s.y); atomicAdd(out + 4 * i + 2, s.z); atomicAdd(out + 4 * i + 3, s.w); }
             }
@@ -241,18 +253,18 @@ void smooth_l1_kernel(const float* __restrict__ out, const float* __restrict__ t
 // token-assembly backward (modeling_cyclical.py:179-192):  dpatch = (1-w) * dx[:,1:],
 // dcls += sum_b dx[b,0], dmask_token += sum_masked dx
 // ------------------------------------------------------------------------------------------
-template <int NV>
-__global__ __launch_bounds__(256)
+template <int NV, int TKB_WAVES>
+__global__ __launch_bounds__(TKB_WAVES * 64)
 void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ mask, bf16* __restrict__ dpatch,
                       float* __restrict__ dcls, float* __restrict__ dmask, int B, int P, int C, int rows_per_block) {
-    __shared__ float red[4][64 * 4];
+    __shared__ float red[TKB_WAVES][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nv = C >> 2, N = P + 1;
     float4 ac[NV], am[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) { ac[k] = make_float4(0.f, 0.f, 0.f, 0.f); am[k] = ac[k]; }
     const int M = B * N;
     const int row_end = min((int)(blockIdx.x + 1) * rows_per_block, M);
-    for (int row = blockIdx.x * rows_per_block + wave; row < row_end; row += 4) {
+    for (int row = blockIdx.x * rows_per_block + wave; row < row_end; row += TKB_WAVES) {
         const int b = row / N, t = row - b * N;
         const bool is_cls = t == 0;
         const bool masked = !is_cls && mask[b * P + t - 1] != 0;
@@ -271,8 +283,10 @@ void token_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ 
             }
         }
     }
-    block_col_atomic(ac, dcls, nv, red);
-    block_col_atomic(am, dmask, nv, red);
+    // a workgroup whose rows hold no cls token has nothing to add to d cls_token (block-uniform test)
+    const int row0 = blockIdx.x * rows_per_block;
+    if ((row0 + N - 1) / N * N < row_end) block_col_atomic<NV, TKB_WAVES>(ac, dcls, nv, red);
+    block_col_atomic<NV, TKB_WAVES>(am, dmask, nv, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,15 +337,18 @@ __global__ void droppath_kernel(float* __restrict__ scales, const float* __restr
 // host's raises a flag behind the counts, which poisons the step's loss (droppath_lists_guard_kernel).
 #define DP_MAX_LISTS 128                     // 2 x UVIT_MAX_DEPTH (include/uvit.h)
 struct DpHostCounts { int k[DP_MAX_LISTS]; };
+#define DPL_CHUNKS 8
 __global__ __launch_bounds__(256)
 void droppath_lists_kernel(const float* __restrict__ scales, int* __restrict__ pos, int* __restrict__ bmap, int* __restrict__ rows,
                            int* __restrict__ cnt, int B, int tokens, int rows_stride, DpHostCounts host) {
+    // grid (lists, DPL_CHUNKS): every workgroup of a list derives the slot / sample maps (a ballot pass per 256 samples; the sample map stays in
+    // LDS), the first one publishes them, and each fills its share of the row list
+    extern __shared__ int s_m[];                      // [B] slot -> sample
     const int lb = blockIdx.x;
     const float* sc = scales + (size_t)lb * B;
     int* p = pos + (size_t)lb * B; int* m = bmap + (size_t)lb * B; int* r = rows + (size_t)lb * rows_stride;
-    // slots by a block-wide prefix count over the keep flags, 256 samples per pass (wave ballots + the four wave totals through LDS)
+    const bool pub = blockIdx.y == 0;
     __shared__ int s_w[4];
-    __shared__ int s_k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
     for (int b0 = 0; b0 < B; b0 += 256) {
@@ -343,23 +360,23 @@ void droppath_lists_kernel(const float* __restrict__ scales, int* __restrict__ p
         int before = base;
         for (int q = 0; q < wave; ++q) before += s_w[q];
         const int slot = before + __popcll(bal & ((1ull << lane) - 1ull));
-        if (b < B) p[b] = keep ? slot : -1;
-        if (keep) m[slot] = b;
+        if (pub && b < B) p[b] = keep ? slot : -1;
+        if (keep) { s_m[slot] = b; if (pub) m[slot] = b; }
         base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    for (int b = base + threadIdx.x; b < B; b += 256) m[b] = 0;
-    if (threadIdx.x == 0) {
-        cnt[lb] = base * tokens;
-        cnt[gridDim.x + lb] = base != host.k[lb];         // checked by droppath_lists_guard_kernel once the loss has been zeroed
-        s_k = base;
+    if (pub) {
+        for (int b = base + threadIdx.x; b < B; b += 256) m[b] = 0;
+        if (threadIdx.x == 0) {
+            cnt[lb] = base * tokens;
+            cnt[gridDim.x + lb] = base != host.k[lb];         // checked by droppath_lists_guard_kernel once the loss has been zeroed
+        }
     }
-    __syncthreads();
-    __threadfence_block();
-    const int n = s_k * tokens, npad = (n + 63) & ~63;
-    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    const int n = base * tokens, npad = (n + 63) & ~63;
+    const int per = (npad + DPL_CHUNKS - 1) / DPL_CHUNKS, lo = blockIdx.y * per, hi = min(lo + per, npad);
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const int slot = i / tokens;
-        r[i] = i < n ? m[slot] * tokens + (i - slot * tokens) : -1;
+        r[i] = i < n ? s_m[slot] * tokens + (i - slot * tokens) : -1;
     }
 }
 
@@ -370,6 +387,14 @@ void droppath_lists_kernel(const float* __restrict__ scales, int* __restrict__ p
     if (_nv <= 1) hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); else if (_nv == 2) hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); \
     else if (_nv == 3) hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); else if (_nv == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); \
     else if (_nv == 5) hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); } while (0)
+
+#define LN_DISPATCH2_TKB(W) do { const int _nv = (C + 255) / 256; const dim3 g_((M + rpb - 1) / rpb), b_((W) * 64); \
+    if (_nv <= 1) hipLaunchKernelGGL((token_bwd_kernel<1, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); \
+    else if (_nv == 2) hipLaunchKernelGGL((token_bwd_kernel<2, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); \
+    else if (_nv == 3) hipLaunchKernelGGL((token_bwd_kernel<3, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); \
+    else if (_nv == 4) hipLaunchKernelGGL((token_bwd_kernel<4, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); \
+    else if (_nv == 5) hipLaunchKernelGGL((token_bwd_kernel<5, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); \
+    else hipLaunchKernelGGL((token_bwd_kernel<8, W>), g_, b_, 0, s, dx, mask, (bf16*)dpatch, dcls, dmask_token, B, P, C, rpb); } while (0)
 
 static inline int grid_for(size_t n, int block, int cap = 256 * 8) {
     size_t g = (n + block - 1) / block;
@@ -436,11 +461,13 @@ int uvit_token_bwd_launch(const float* dx, const int64_t* mask, void* dpatch, fl
     // 32-row workgroups (788 of them at bs = 128) those contended atomics were most of the kernel's 169 us.  One
     // workgroup per CU-slot instead: <= 512 workgroups.
     const int M = B * (P + 1);
-    int rpb = (M + 511) / 512;
-    rpb = ((rpb + 3) / 4) * 4;
-    if (rpb < CP_ROWS) rpb = CP_ROWS;
-    CP_DISPATCH(token_bwd_kernel, C, dim3((M + rpb - 1) / rpb), dim3(256), 0, s, dx, mask, (bf16*)dpatch,
-                       dcls, dmask_token, B, P, C, rpb);
+    // (end of round 4: 16-wave workgroups, <= 128 of them -- the same rows in flight as 512 4-wave ones with a quarter of the same-address adders,
+    //  and a workgroup without a cls row skips that column sum: 111 -> 43 us alone; inside the two-stream step, where it shares the CUs with the
+    //  last wgrad, the step time does not change)
+    int rpb = (M + 127) / 128;
+    rpb = ((rpb + 15) / 16) * 16;
+    if (rpb < 32) rpb = 32;
+    LN_DISPATCH2_TKB(16);
     return uvit_check_launch();
 }
 int uvit_transpose_batch_launch(const void* descs_dev, int ndesc, int total_tiles, hipStream_t s) {
@@ -467,7 +494,7 @@ int uvit_droppath_lists_launch(const float* scales, int* pos, int* bmap, int* ro
     if (nlists < 1 || nlists > DP_MAX_LISTS || rows_stride < ((B * tokens + 63) & ~63)) return UVIT_ERR_ARG;
     DpHostCounts h;
     for (int i = 0; i < DP_MAX_LISTS; ++i) h.k[i] = i < nlists ? host_counts[i] : 0;
-    hipLaunchKernelGGL(droppath_lists_kernel, dim3(nlists), dim3(256), 0, s, scales, pos, bmap, rows, cnt, B, tokens, rows_stride, h);
+    hipLaunchKernelGGL(droppath_lists_kernel, dim3(nlists, DPL_CHUNKS), dim3(256), (size_t)B * sizeof(int), s, scales, pos, bmap, rows, cnt, B, tokens, rows_stride, h);
     return uvit_check_launch();
 }
 

@@ -1096,13 +1096,22 @@ extern "C" int uvit_step_backward_embed(uvit_engine* e, uvit_stream stream) {
     Layout& lo = e->lo;
     float* g = e->buf.grads;
     const int C = e->C, BP = e->BP;
+    // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output; then the patch-embedding weight gradient and
+    // its bias column sum as ONE grouped launch (end of round 4; was a column-sum launch and the plain TN kernel per stream, 137 us each at the
+    // very end of backward) when the shapes qualify
+    TnProb pe[2];
     for (int st = 0; st < e->S; ++st) {
-        // token assembly backward: d cls_token, d mask_token, gradient of the patch-embedding output
         CHECK(uvit_token_bwd_launch(e->dXa + (size_t)st * e->Mpad * C, e->mask_copy, e->dpatch[st], g + (st ? lo.ccls : lo.cls),
                                     g + (st ? lo.cmask_tok : lo.mask_tok), e->B, e->P, C, s));
-        CHECK(uvit_colsum_launch(e->dpatch[st], C, 0, C, BP, RP(st ? lo.cpeb : lo.peb), NREP, e->n_nd, s));
-        CHECK(GEMM_TN(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
+        TnProb& q = pe[st]; q.Y = e->dpatch[st]; q.X = e->cols; q.C = g + (st ? lo.cpew : lo.pew); q.M = (int)roundup(BP, 64); q.Nn = C; q.Kk = e->Kpe;
+        q.ldy = C; q.ldx = e->Kpe; q.ldc = e->Kpe; q.bias = RP(st ? lo.cpeb : lo.peb); q.bias_end = C;
     }
+    if (uvit_gemm_tn_group_ok(pe, e->S, &e->tune)) CHECK(GEMM_TN_GROUP(pe, e->S, s));
+    else
+        for (int st = 0; st < e->S; ++st) {
+            CHECK(uvit_colsum_launch(e->dpatch[st], C, 0, C, BP, RP(st ? lo.cpeb : lo.peb), NREP, e->n_nd, s));
+            CHECK(GEMM_TN(e->dpatch[st], e->cols, (int)roundup(BP, 64), C, e->Kpe, C, e->Kpe, g + (st ? lo.cpew : lo.pew), e->Kpe, 1, s));
+        }
     if (e->cfg.use_abs_pos_emb) CHECK(uvit_pos_bwd_launch(e->dXa, g + lo.pos, e->B, e->N, C, s));     // d pos_embed = sum_b dX[b]
     if (e->dual) HIPCHECK(hipStreamWaitEvent(s, e->ev_wdone[0], 0));   // every wgrad / bias sum / bias-gradient reduction has landed
     if (e->cfg.use_shared_rel_pos_bias && e->slab_started)
@@ -1125,6 +1134,8 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
     if (hp->sched_dev && (hp->sched_len < 1 || hp->sched_index < 0 || hp->sched_index >= hp->sched_len)) return UVIT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     Layout& lo = e->lo;
+    // (end of round 4, measured and removed: summing each block's share of the clip norm behind its wgrad on the second stream, which leaves
+    //  5 MB instead of 345 MB for this pass -- the 12 streaming launches take CUs from the dgrad chain: 23.76 vs 23.54 ms per step, 4 rotated pairs)
     HIPCHECK(hipMemsetAsync(e->sumsq, 0, sizeof(double), s));
     CHECK(uvit_sumsq_launch(e->buf.grads, lo.n_live, e->sumsq, s));
     const float gs = hp->grad_scale > 0.f ? hp->grad_scale : 1.0f;

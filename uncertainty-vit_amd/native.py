@@ -184,14 +184,17 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise UvitError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    # A/B runs of two builds in one gpurun call (tools/ab.sh "UVIT_LIB_AB=uncertainty-vit_amd/libuvit_prev.so" ...): load another build of
+    # the same ABI instead; the staleness check below does not apply to it
+    alt = os.environ.get("UVIT_LIB_AB")
+    L = C.CDLL(os.path.abspath(alt) if alt else LIB_PATH)
     for name, (res, args) in _PROTOTYPES.items():
         f = getattr(L, name)          # AttributeError here = a symbol of include/uvit.h is missing
         f.restype, f.argtypes = res, args
     if L.uvit_version() != 100:
         raise UvitError("libuvit version mismatch")
     built, want = L.uvit_source_hash().decode(), source_hash()
-    if built != want:
+    if built != want and not alt:
         # never auto-build here: lib() runs inside profiled / multi-rank processes
         raise UvitError(f"{LIB_PATH} is stale: built from sources {built}, on disk {want}. "
                         "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
