@@ -234,6 +234,10 @@ def test_dropout_step_matches_oracle_with_replayed_masks():
     assert st["loss"] == pytest.approx(ref.loss, rel=5e-3)
     assert st["grad_norm"] == pytest.approx(ref.grad_norm, rel=3e-2)
     assert any(t is not None and (t == 0).any() for t in p1 + p2), "test should exercise a dropped path"
+    # the step ran with the drop-path sample lists (compact branches); every gradient against the oracle, which multiplies dropped branches by 0
+    assert model._engine.drop_path_rows
+    grads = {n: q.grad for n, q in model.named_parameters()}
+    assert_grads_close(grads, ref.grads, what="[drop-path lists vs oracle] ")
 
 
 def test_vit_large_step_vs_oracle():
