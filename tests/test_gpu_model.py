@@ -374,15 +374,19 @@ def test_batch_and_instance_norm_target_variants(golden_dir, case):
             assert (g - r).norm() <= 2e-2 * r.norm(), (n, float((g - r).norm() / r.norm()))
 
 
-@pytest.mark.parametrize("shape", ["tiny", "vitb8", "vitb32_hint"])
+@pytest.mark.parametrize("shape", ["tiny", "vitb8", "vitb32_hint", "wide1024"])
 def test_drop_path_sample_lists_equal_all_samples(shape):
     """uvit_engine_set_drop_path_rows (include/uvit.h): a Block branch whose DropPath dropped a sample is multiplied by 0 for it in the
     forward and receives no gradient (modeling_finetune.py:51-62, 295-298), so the step runs each branch on the kept samples only, in compact
     rows.  Same model, batch and seeds with the lists on and off: same loss, same gradients (the weight gradients sum the same non-zero rows in
     another order), same targets.  `tiny` has ungrouped wgrads and 10-token samples (compact row counts that are no multiple of 64),
     `vitb8` is ViT-B/16 with drop_path 0.5 (a third of the samples dropped per branch on average), `vitb32_hint` adds the masked-row last
-    block (n_rows_hint), whose MLP keeps its own row list while the layers below run the sample lists."""
-    if shape == "tiny":
+    block (n_rows_hint), whose MLP keeps its own row list while the layers below run the sample lists; `wide1024` has ViT-L's row length
+    (C = 1024, 16 heads: the four-float4-per-lane instantiations of the LayerNorm kernels) on three blocks."""
+    if shape == "wide1024":
+        cfg = vo.VitConfig(embed_dim=1024, depth=3, num_heads=16, init_values=0.1, drop_path_rate=0.5, attn_drop_rate=0.05)
+        B, img, P, nm, tl = 8, 224, 196, 75, [1, 2]
+    elif shape == "tiny":
         cfg = vo.VitConfig(img_size=48, embed_dim=128, depth=4, num_heads=2, init_values=0.1, drop_path_rate=0.5, attn_drop_rate=0.1)
         B, img, P, nm, tl = 12, 48, 9, 4, [2, 3]
     else:
