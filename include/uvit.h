@@ -185,6 +185,10 @@ int uvit_engine_set_streams(uvit_engine* e, int dual);
  * are multiplied by 0, as the reference does.  Same results either way (bench.py reports both rates).  Environment UVIT_DP_ROWS=0
  * selects 0 at engine creation. */
 int uvit_engine_set_drop_path_rows(uvit_engine* e, int on);
+/* The host side of those lists, callable without a GPU: kept samples per (layer, draw) for one step -- out[draws_per_block * layer + k],
+ * draws_per_block = 2 (base: attn, mlp) or 4 (two-stream: mean attn, mean mlp, cov attn, cov mlp) -- from the counter-based hash the device
+ * draws its DropPath multipliers with (rates linspace(0, drop_path_rate, depth), modeling_cyclical.py:94-96).  Pure host arithmetic. */
+int uvit_drop_path_kept_counts(int depth, float drop_path_rate, int draws_per_block, int batch, uint32_t seed, uint32_t it, int32_t* out);
 /* Measurement aid for bench.py: bracket every launch of the dominant kernel (the fc1 GEMM with
  * fused bias+GELU, gemm_nt256_kernel<EPI_GELU / EPI_GELU_DG>) with HIP events on the stream it runs on.
  * profile_read: sum of the event-bracketed durations (ms), launch count, algorithmic FLOPs per launch. */

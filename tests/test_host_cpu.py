@@ -466,3 +466,27 @@ def test_mfma_hazard_guard_flags_the_broken_stream_and_passes_the_tree():
     r = subprocess.run([sys.executable, tool, "--compile", os.path.join(csrc, "attention.hip"), os.path.join(csrc, "attention2.hip")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("draws,depth,B,rate", [(2, 12, 128, 0.25), (2, 24, 64, 0.4), (4, 12, 128, 0.25), (2, 3, 6, 0.3), (4, 4, 12, 0.5)])
+def test_host_side_drop_path_counts_match_the_oracle_draws(native, draws, depth, B, rate):
+    """uvit_drop_path_kept_counts (include/uvit.h): the engine sizes the compact launches of a step (drop-path sample lists) from ITS evaluation of
+    the counter-based hash the device draws the DropPath multipliers with.  Pure host arithmetic, so it is pinned here, without a GPU, against
+    the oracle's replay of the same draws (oracle/vit_oracle.py::drop_path_scales, oracle/vit_oracle_dist.py::drop_path_scales: the masks the
+    GPU parity steps replay) over several seeds and iterations -- kept samples per (layer, draw)."""
+    from oracle import vit_oracle_dist as vd
+    L = native.lib()
+    cfg = vo.VitConfig(depth=depth, drop_path_rate=rate)
+    for seed, it in [(0, 0), (1234, 7), (0xFFFFFFFF, 3), (99, 100000)]:
+        out = (C.c_int32 * (draws * depth))()
+        assert L.uvit_drop_path_kept_counts(depth, C.c_float(rate), draws, B, C.c_uint32(seed), C.c_uint32(it), out) == 0
+        got = np.array(out[:]).reshape(depth, draws)
+        if draws == 2:
+            p1, p2 = vo.drop_path_scales(seed, it, cfg, B)
+            cols = [p1, p2]
+        else:
+            cols = vd.drop_path_scales(seed, it, cfg, B)
+        want = np.array([[B if cols[k][l] is None else int((cols[k][l] != 0).sum()) for k in range(draws)] for l in range(depth)])
+        assert (got == want).all(), (seed, it, got.tolist(), want.tolist())
+        assert (got[0] == B).all() and (rate == 0 or got.min() < B)          # rate 0 in the first block; somebody is dropped further up
+    assert L.uvit_drop_path_kept_counts(depth, C.c_float(rate), 3, B, 0, 0, out) != 0      # draws per block: 2 or 4

@@ -204,6 +204,7 @@ struct Bump {
 };
 
 static size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
+static std::vector<float> dp_rates_linspace(int depth, float rate);
 
 static void plan_workspace(uvit_engine* e, Bump& b) {
     const uvit_config& c = e->cfg;
@@ -340,9 +341,7 @@ extern "C" uvit_engine* uvit_engine_create(const uvit_config* cfg, const uvit_bu
     // pad rows of every activation buffer must be (and stay) zero: TN GEMMs reduce over them
     if (hipMemsetAsync(bufs->workspace, 0, b.off, s) != hipSuccess) { delete e; return fail(UVIT_ERR_LAUNCH); }
     // drop-path rates linspace(0, rate, depth)  (modeling_cyclical.py:94-96)
-    std::vector<float> rates(cfg->depth);
-    for (int i = 0; i < cfg->depth; ++i)
-        rates[i] = cfg->depth > 1 ? (float)((double)cfg->drop_path_rate * i / (cfg->depth - 1)) : 0.f;
+    std::vector<float> rates = dp_rates_linspace(cfg->depth, cfg->drop_path_rate);
     e->dp_rates_host = rates;
     if (const char* v = getenv("UVIT_DP_ROWS")) e->dpl_enable = v[0] != '0';     // A/B switch (uvit_engine_set_drop_path_rows)
     // transposed-copy descriptors
@@ -550,24 +549,44 @@ static bool dp_list2(const uvit_engine* e, int l, DpList (&d)[2]) {
     dp_list_get(e, l, 0, 1, d[0]); dp_list_get(e, l, 1, 1, d[1]);
     return d[0].K > 0 && d[1].K > 0 && (d[0].K < e->B || d[1].K < e->B);
 }
+// The host's evaluation of droppath_kernel (elementwise.hip): kept samples per (layer, draw), draws = 2 (base: attn, mlp) or 4 (two-stream).
+// Pure host code -- no device call -- so the CPU test suite pins it against the oracle's drop_path_scales.
+static void dp_kept_counts(const float* rates, int depth, int nbr, int B, uint32_t seed, uint32_t it, int* out) {
+    for (int l = 0; l < depth; ++l)
+        for (int br = 0; br < nbr; ++br) {
+            const float r = rates[l];
+            int K = B;
+            if (r > 0.f) {
+                const uint32_t key = uvit_hash32(seed ^ ((it * (uint32_t)nbr * depth + (uint32_t)nbr * l + br + 1u) * 0x9E3779B9u));
+                const uint32_t thr = uvit_drop_threshold(r);
+                K = 0;
+                for (int b = 0; b < B; ++b) K += uvit_hash32((uint32_t)b ^ key) >= thr ? 1 : 0;
+            }
+            out[nbr * l + br] = K;
+        }
+}
+static std::vector<float> dp_rates_linspace(int depth, float rate) {     // drop-path rates linspace(0, rate, depth)  (modeling_cyclical.py:94-96)
+    std::vector<float> rates(depth);
+    for (int i = 0; i < depth; ++i) rates[i] = depth > 1 ? (float)((double)rate * i / (depth - 1)) : 0.f;
+    return rates;
+}
+extern "C" int uvit_drop_path_kept_counts(int depth, float drop_path_rate, int draws_per_block, int B, uint32_t seed, uint32_t it,
+                                          int32_t* out) {
+    if (depth < 1 || depth > UVIT_MAX_DEPTH || (draws_per_block != 2 && draws_per_block != 4) || B < 1 || !out) return UVIT_ERR_ARG;
+    const std::vector<float> rates = dp_rates_linspace(depth, drop_path_rate);
+    dp_kept_counts(rates.data(), depth, draws_per_block, B, seed, it, out);
+    return UVIT_OK;
+}
 static int dp_lists_begin(uvit_engine* e, uint32_t seed, uint32_t it, int Bc, hipStream_t s) {
     const int depth = e->cfg.depth, nbr = 2 * e->S;
     e->dpl_on = false;
     if (!e->dpl_pos) return UVIT_OK;
+    dp_kept_counts(e->dp_rates_host.data(), depth, nbr, Bc, seed, it, e->dpl_K);
     bool any = false;
-    for (int l = 0; l < depth; ++l)
-        for (int br = 0; br < nbr; ++br) {
-            const float r = e->dp_rates_host[l];
-            int K = Bc;
-            if (r > 0.f) {                                 // droppath_kernel, on the host
-                const uint32_t key = uvit_hash32(seed ^ ((it * (uint32_t)nbr * depth + (uint32_t)nbr * l + br + 1u) * 0x9E3779B9u));
-                const uint32_t thr = uvit_drop_threshold(r);
-                K = 0;
-                for (int b = 0; b < Bc; ++b) K += uvit_hash32((uint32_t)b ^ key) >= thr ? 1 : 0;
-            }
-            e->dpl_K[nbr * l + br] = K;
-            any = any || (K > 0 && K < Bc && (e->S == 1 || (br & 1)));
-        }
+    for (int i = 0; i < nbr * depth; ++i) {
+        const int K = e->dpl_K[i], br = i % nbr;
+        any = any || (K > 0 && K < Bc && (e->S == 1 || (br & 1)));
+    }
     e->dpl_on = any;
     if (!any) return UVIT_OK;
     return uvit_droppath_lists_launch(e->dp_scales, e->dpl_pos, e->dpl_bmap, e->dpl_rows, e->dpl_cnt, nbr * depth, Bc, e->N,

@@ -113,6 +113,7 @@ _PROTOTYPES = {
     "uvit_op_wgrad_group": (_i, [_vp, _i, _vp, _vp]),
     "uvit_engine_set_streams": (_i, [_vp, _i]),
     "uvit_engine_set_drop_path_rows": (_i, [_vp, _i]),
+    "uvit_drop_path_kept_counts": (_i, [_i, _f, _i, _i, _u32, _u32, _vp]),
     "uvit_engine_profile": (_i, [_vp, _i, _i]),
     "uvit_engine_profile_read": (_i, [_vp, _vp, _vp, _vp]),
     "uvit_engine_profile_read_kind": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
