@@ -1162,7 +1162,8 @@ extern "C" int uvit_step_update(uvit_engine* e, const uvit_step_params* hp, uvit
                             hp->lr, hp->weight_decay, hp->beta1, hp->beta2, hp->eps, hp->opt_step, e->sumsq, hp->clip_grad, gs,
                             e->gnorm, s, e->loss, (hp->do_ema || hp->sched_dev) ? e->buf.ema : nullptr, e->buf.ema_bf16, hp->ema_decay, e->poisoned,
                             hp->sched_dev, hp->sched_len, hp->sched_index));
-    // (round 4 tried these transposed copies on the second stream, beside the next forward: 24.9-25.2 vs 24.7-25.2 ms per step, no gain)
+    // (round 4 tried these transposed copies on the second stream, beside the next forward: 24.9-25.2 vs 24.7-25.2 ms per step, no gain; again at the
+    //  end of the round with the order-rotated A/B, five pairs: 23.47 vs 23.43 ms)
     CHECK(uvit_transpose_batch_launch(e->tdesc, e->n_tdesc, e->n_ttiles, s));
     // frozen tensors (two-stream cov_qkv.weight) sit behind n_live: AdamW never touches them, the reference's EMA does
     // average them (ModelEmaV2 walks every state-dict value) -- a no-op on values that never change, skipped
