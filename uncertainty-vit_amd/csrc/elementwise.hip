@@ -303,6 +303,27 @@ void transpose_batch_kernel(const TransposeDesc* __restrict__ descs, int ndesc) 
     const int tr0 = (local / tc) * 64, tc0 = (local % tc) * 64;
     if (tr0 >= d.rows) return;
     const bf16* src = (const bf16*)d.src; bf16* dst = (bf16*)d.dst;
+    if (tr0 + 64 <= d.rows && tc0 + 64 <= d.cols && !(d.rows & 7) && !(d.cols & 7)) {
+        // whole tile (every Linear weight of the models: dimensions are multiples of 64): 16 B per lane on both sides (end of round 4; the
+        // element-wise form below moved 2 B per lane and ran at 2.5 TB/s: 139 us at the very end of every step)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + 256 * k, r = idx >> 3, c8 = (idx & 7) * 8;
+            const bf16x8 v = *(const bf16x8*)(src + (size_t)(tr0 + r) * d.cols + tc0 + c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[r][c8 + j] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = threadIdx.x + 256 * k, oc = idx >> 3, r8 = (idx & 7) * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = tile[r8 + j][oc];
+            *(bf16x8*)(dst + (size_t)(tc0 + oc) * d.rows + tr0 + r8) = o;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         tile[r][c] = (tr0 + r < d.rows && tc0 + c < d.cols) ? src[(size_t)(tr0 + r) * d.cols + tc0 + c] : f2bf(0.f);
