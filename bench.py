@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-input-staging", action="store_true", help="skip the two extra short regions that time H2D-fed and device-synthesised batches")
     ap.add_argument("--single-stream", action="store_true", help="no second HIP stream (per-kernel profiling runs)")
-    ap.add_argument("--all-rows", action="store_true", help="no masked-row bound for the step: the last block's MLP runs on every token row (A/B of uvit_step_params.n_rows_hint)")
+    ap.add_argument("--all-rows", action="store_true", help="every row and every sample through every branch: no masked-row bound for the last block's MLP (uvit_step_params.n_rows_hint) "
+                                                            "and no drop-path sample lists (uvit_engine_set_drop_path_rows) -- the full-size launches")
     ap.add_argument("--no-alone", action="store_true", help="skip the 3 extra single-stream steps that time the dominant kernel alone (profiling runs of the two-stream schedule)")
     ap.add_argument("--grad-comm-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce buckets (bf16 halves the xGMI bytes; AdamW accumulates in fp32 either way)")
@@ -271,6 +272,8 @@ def main():
     builtins.print = _p
     opt._ensure_state()
     engine = model.engine(a.batch, teacher=ema.module, adam_m=opt.exp_avg, adam_v=opt.exp_avg_sq)
+    if a.all_rows:
+        engine.set_drop_path_rows(False)
     reducer = GradReducer(model, world > 1, comm_dtype=torch.bfloat16 if a.grad_comm_dtype == "bf16" else torch.float32)
     x, mask = synthetic_batch(a.batch, 1000 + rank, dev)
     mask = mask.reshape(a.batch, -1).contiguous()

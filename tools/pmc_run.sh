@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/${tag}
 mkdir -p $out
 cd /tmp
-export UVIT_DP_ROWS=0      # full-size launches: every branch on every sample (the shapes bench.py's per-launch traffic figures are quoted for)
+# (--all-rows below = full-size launches: no masked-row bound, every branch on every sample -- the shapes bench.py quotes per-launch traffic for)
 # optional third / fourth pass (PMC_EXTRA="TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum", when `rocprofv3 -L` lists them): the requests that
 # reach HBM itself -- FETCH_SIZE / WRITE_SIZE count the L2's fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM)
 for c in FETCH_SIZE WRITE_SIZE $PMC_EXTRA; do
