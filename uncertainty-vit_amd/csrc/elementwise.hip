@@ -471,7 +471,8 @@ int uvit_colsum_launch(const void* y, int ld, int col0, int ncols, int M, float*
 int uvit_smooth_l1_launch(const float* out, const float* target, const int* count, float beta, int l2, float loss_scale,
                           float* loss, void* dout, int Mmax, int C, hipStream_t s) {
     if (C % 4) return UVIT_ERR_SHAPE;
-    hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for((size_t)Mmax * C / 4, 256)), dim3(256), 0, s, out, target, count, beta, l2,
+    // (<= 512 workgroups: every workgroup ends with one atomic on the same loss word)
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(grid_for((size_t)Mmax * C / 4, 256, 512)), dim3(256), 0, s, out, target, count, beta, l2,
                        loss_scale, loss, (bf16*)dout, Mmax, C);
     return uvit_check_launch();
 }

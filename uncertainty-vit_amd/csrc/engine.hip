@@ -889,8 +889,15 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     const bf16* wt = (const bf16*)e->buf.params_bf16_t;
     for (int st = 0; st < e->S; ++st) {
         const size_t lmw = st ? lo.clmw : lo.lmw, lmb = st ? lo.clmb : lo.lmb;
-        CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, Rh, RP(lmb), NREP, e->n_nd, s));
-        CHECK(GEMM_TN(e->dout[st], e->normed[st], e->compact_R > 0 ? e->compact_R : e->BPpad, C, C, C, C, g + lmw, C, 1, s));
+        // lm_head weight gradient + bias column sum: one launch of the grouped wgrad kernel when the shapes qualify (was a column-sum launch
+        // and the plain TN kernel, 50 us, on the critical chain between the loss and the first dgrad)
+        TnProb hw; hw.Y = e->dout[st]; hw.X = e->normed[st]; hw.C = g + lmw; hw.M = e->compact_R > 0 ? e->compact_R : e->BPpad; hw.Nn = C; hw.Kk = C;
+        hw.ldy = C; hw.ldx = C; hw.ldc = C; hw.bias = RP(lmb); hw.bias_end = C;
+        if (uvit_gemm_tn_group_ok(&hw, 1, &e->tune)) CHECK(GEMM_TN_GROUP(&hw, 1, s));
+        else {
+            CHECK(uvit_colsum_launch(e->dout[st], C, 0, C, Rh, RP(lmb), NREP, e->n_nd, s));
+            CHECK(GEMM_TN(e->dout[st], e->normed[st], e->compact_R > 0 ? e->compact_R : e->BPpad, C, C, C, C, g + lmw, C, 1, s));
+        }
         GemmEpi d; d.out = e->dnormed[st]; d.ldo = C;
         CHECK(GEMM_NT(EPI_BF16, e->dout[st], wt + lmw, Rh, C, C, C, C, &d, s));
         // final LayerNorm backward scattered into the (zeroed) residual-stream gradient
