@@ -100,7 +100,8 @@ typedef struct uvit_step_params {
     /* Upper bound on the number of masked patches of this batch (the loader has bool_masked_pos on the host before the upload), 0 = not
      * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the base model's last
      * block runs its MLP -- forward, dgrads and wgrads -- on those rows alone; results equal the all-rows step.  A bound BELOW the true count
-     * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model ignores it. */
+     * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model runs the R rows of each stream, stacked, through the shared
+     * fc1 / fc2. */
     int32_t n_rows_hint;
 } uvit_step_params;
 
