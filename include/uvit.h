@@ -95,10 +95,11 @@ typedef struct uvit_step_params {
     int32_t layer_results_fc;         /* --layer_results fc: targets from the teacher's MLP-branch outputs (modeling_cyclical.py:199-205) */
     float var_w0, var_margin0;        /* variance term, engine_for_cyclical.py:130-139,161 (var_w0 <= 0: off) */
     /* target-builder variants (engine_for_cyclical.py:94-118): affine-free batch norm over (B, T) per channel, instance norm
-     * over T per (sample, channel) on every target layer; instance norm of the layer average.  Base model only. */
+     * over T per (sample, channel) on every target layer; instance norm of the layer average.  Both models: with the two-stream model they act
+     * on the MEAN targets (the covariance targets, :73-86, only know the two layer-norm flags). */
     int32_t target_batch_norm, target_instance_norm, post_target_instance_norm;
     /* Upper bound on the number of masked patches of this batch (the loader has bool_masked_pos on the host before the upload), 0 = not
-     * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the base model's last
+     * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the last
      * block runs its MLP -- forward, dgrads and wgrads -- on those rows alone; results equal the all-rows step.  A bound BELOW the true count
      * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model runs the R rows of each stream, stacked, through the shared
      * fc1 / fc2. */
