@@ -341,7 +341,7 @@ def main():
         check(L.uvit_engine_set_streams(engine.h, engine.stream_mode), "set_streams")
     # the step without the masked-row bound (every row through the last block's MLP): img/s beside `value`, same run
     all_rows_value = None
-    if world == 1 and feed["mask_rows"] and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)
+    if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)
         keep = feed["mask_rows"]
         feed["mask_rows"] = 0
         keep_dp = engine.drop_path_rows
@@ -372,23 +372,18 @@ def main():
         # FLOPs the step really executes: with the masked-row bound the last block's MLP (teacher forward; student forward, two
         # dgrads, two wgrads = 8 GEMMs of 2 rows C Hd) skips the rows that feed neither the loss nor the targets
         M_rows, Cd, Hdd = a.batch * 197, model.embed_dim, 4 * model.embed_dim
-        n_str = 2 if stochastic else 1                  # the two-stream model runs the masked-row MLP per stream
-        skipped = n_str * 16.0 * max(M_rows - feed["mask_rows"], 0) * Cd * Hdd / a.batch / 1e9 if feed["mask_rows"] else 0.0
+        skipped = 16.0 * max(M_rows - feed["mask_rows"], 0) * Cd * Hdd / a.batch / 1e9 if (feed["mask_rows"] and not stochastic) else 0.0
         # drop-path sample lists (base model): a student branch skips the samples its DropPath dropped -- in expectation rate_l of them in
         # layer l (rates linspace(0, 0.25, depth)); per token the attention branch is 8 C^2 (QKV, proj) + 4 N C (core), the MLP 16 C^2, and
         # the student runs them forward + backward (x3; the attention core's backward is 2.5 forwards).  The masked-row last block keeps
         # the dense attention branch and its own row list.
-        dp_lists = bool(engine.drop_path_rows)
+        dp_lists = bool(engine.drop_path_rows) and not stochastic
         skipped_dp = 0.0
         if dp_lists:
             depth_ = model.depth
-            for l_ in range(depth_):
+            for l_ in range(depth_ - 1 if feed["mask_rows"] else depth_):
                 r_ = 0.25 * l_ / (depth_ - 1)
-                last_masked = bool(feed["mask_rows"]) and l_ == depth_ - 1      # that block's MLP keeps its masked-row list instead
-                if stochastic:                                              # two-stream: the MLP branches only, per stream
-                    skipped_dp += 0.0 if last_masked else 2 * r_ * 197 * (3 * 16 * Cd * Cd) / 1e9
-                else:
-                    skipped_dp += r_ * 197 * (3 * 8 * Cd * Cd + 3.5 * 4 * 197 * Cd + (0 if last_masked else 3 * 16 * Cd * Cd)) / 1e9
+                skipped_dp += r_ * 197 * (3 * 8 * Cd * Cd + 3.5 * 4 * 197 * Cd + 3 * 16 * Cd * Cd) / 1e9
         skipped += skipped_dp
         traffic = pmc_traffic()
         rp = rocprof_avg_us()
@@ -440,7 +435,7 @@ def main():
                        "value_all_rows": all_rows_value,
                        "final_loss": round(float(stats[0]), 5),
                        "last_block_mlp_rows": (f"{feed['mask_rows']} masked rows of {a.batch * 197} (host-side bound; same results as all rows)"
-                                               if feed["mask_rows"] else "all"),
+                                               if feed["mask_rows"] and not stochastic else "all"),
                        "drop_path_rows": ("each Block branch of the student runs on the samples its DropPath kept (compact rows sized on the host from the "
                                           f"device's counter-based hash; same results as all samples); expected skip {skipped_dp:.2f} GFLOP/image"
                                           if dp_lists else "all samples"),

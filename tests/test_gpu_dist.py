@@ -446,46 +446,3 @@ def test_two_stream_drop_path_lists_equal_all_samples(shape):
     errs = {n: float((gl[n] - r).norm() / (r.norm() + 1e-30)) for n, r in ga.items()}
     bad = {n: v for n, v in errs.items() if v > (1e-2 if ga[n].dim() >= 2 else 5e-2)}
     assert not bad, bad
-
-
-@pytest.mark.parametrize("dropout", [False, True])
-def test_two_stream_last_block_on_masked_rows_equals_all_rows(dropout):
-    """uvit_step_params.n_rows_hint on the two-stream model (end of round 4): with a host-side bound on the masked patches the last block's MLP
-    runs on the masked rows of each stream, stacked in front of the shared fc1 / fc2 (student and teacher).  Same model, batch and seeds with
-    the bound (CPU mask: counted on the host) and without (GPU mask): same loss, same gradients; with dropout the layers below run the
-    drop-path sample lists in both runs.  ViT-B/16, B = 8, ragged masks."""
-    from uncertainty_vit_amd import engine_for_cyclical as eng, optim_factory, utils
-    from uncertainty_vit_amd.modeling_cyclical import DistVisionTransformerForCyclicalTraining
-    from oracle.closed_form import exact_masks
-    kw = dict(img_size=224, embed_dim=768, depth=12, num_heads=12)
-    dpr, adr = (0.25, 0.05) if dropout else (0.0, 0.0)
-    cfg = vo.VitConfig(init_values=0.1, drop_path_rate=dpr, attn_drop_rate=adr, **kw)
-    x, mask = closed_form_images("drows", 8, 224), exact_masks(8, 196, 75, 5)
-    mask[3, :] = False; mask[3, :4] = True
-
-    class A:
-        opt, lr, weight_decay, opt_eps, opt_betas = "adamw", 2e-3, 0.05, 1e-8, (0.9, 0.999)
-    res = {}
-    for mode in ("all", "rows"):
-        model = DistVisionTransformerForCyclicalTraining(patch_size=16, mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
-                                                         init_values=0.1, use_shared_rel_pos_bias=True, use_abs_pos_emb=False, drop_path_rate=dpr,
-                                                         attn_drop_rate=adr, **kw)
-        model.load_state_dict(closed_form_state(vd.param_shapes(cfg), gamma=0.1), strict=False)
-        model = model.cuda()
-        if dropout:
-            model.train()
-        ema = utils.ModelEmaV2(model, decay=0.9998)
-        opt = optim_factory.create_optimizer(A(), model)
-        torch.manual_seed(77)
-        batch = (x.cuda(), mask.cuda()) if mode == "all" else (x, mask)
-        st = eng.train_one_epoch(model, ema, 0, 0.9998, 0.9998, list(range(6, 12)), [(batch, torch.zeros(1))], opt, torch.device("cuda"), 0,
-                                 utils.NativeScalerWithGradNormCount(), max_norm=3.0, l1_beta=2.0, start_steps=1, layer_results="end",
-                                 loss_scale=-1, target_layer_norm_last=True, post_target_layer_norm=True, stochastic=True,
-                                 lambda_pretraining=1e-2)
-        res[mode] = (st, {n: q.grad.detach().float().cpu().clone() for n, q in model.named_parameters() if q.grad is not None})
-        assert (model._engine.compact_rows() > 0) == (mode == "rows")
-    (sa, ga), (sr, gr) = res["all"], res["rows"]
-    assert sr["loss"] == pytest.approx(sa["loss"], rel=2e-5) and sr["grad_norm"] == pytest.approx(sa["grad_norm"], rel=2e-4)
-    errs = {n: float((gr[n] - r).norm() / (r.norm() + 1e-30)) for n, r in ga.items()}
-    bad = {n: v for n, v in errs.items() if v > (1e-2 if ga[n].dim() >= 2 else 5e-2)}
-    assert not bad, bad

@@ -593,8 +593,7 @@ static int dp_lists_begin(uvit_engine* e, uint32_t seed, uint32_t it, int Bc, hi
                                       (int)e->dpl_stride, e->dpl_K, s);
 }
 
-// R > 0 (student's last block of a training step; the teacher's last block with a masked-row target builder): the MLP branch runs on the R compact
-// rows of the masked-patch list only (two-stream model: the R rows of each stream, stacked) --
+// R > 0 (base model, student's last block of a training step): the MLP branch runs on the R compact rows of the masked-patch list only --
 // LN2 gathers them, fc1 / fc2 are R-row GEMMs and the residual epilogue of fc2 reads x_mid and writes x_out / the saved branch output at the
 // listed rows (the other rows of x_out are never read: the head and the final-norm backward go through the same list).
 static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x_in, float* x_mid, float* x_out,
@@ -643,19 +642,15 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         prof_end(pp);
     }
     DpList d2[2] = {};
-    const bool lm2 = lists && R == 0 && S == 2 && Bc == e->B && dp_list2(e, l, d2);
-    const size_t off2[2] = {0, lm2 ? (size_t)d2[0].K * e->N : (R > 0 ? (size_t)R : Mp)};       // first compact row of each stream's MLP rows
-    const int Mm = lm ? dm.K * e->N : (lm2 ? (d2[0].K + d2[1].K) * e->N : (R > 0 ? S * R : Mall));
+    const bool lm2 = lists && S == 2 && Bc == e->B && dp_list2(e, l, d2);
+    const size_t off2[2] = {0, lm2 ? (size_t)d2[0].K * e->N : Mp};       // first compact row of each stream's MLP rows
+    const int Mm = lm ? dm.K * e->N : (lm2 ? (d2[0].K + d2[1].K) * e->N : (R > 0 ? R : Mall));
     if (lm2) {
         for (int st = 0; st < 2; ++st)
             CHECK(uvit_ln_fwd_keep_launch(x_mid + st * Mp * C, d2[st].pos, w.f + o.n2w, w.f + o.n2b, a.ln2 + off2[st] * C, a.mean2 + off2[st],
                                           a.rstd2 + off2[st], x_out + st * Mp * C, M, C, e->N, e->cfg.ln_eps, s));
     } else
-    if (R > 0) {
-        for (int st = 0; st < S; ++st)
-            CHECK(uvit_ln_fwd_gather_launch(x_mid + st * Mp * C, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2 + off2[st] * C,
-                                            a.mean2 + off2[st], a.rstd2 + off2[st], R, C, e->cfg.ln_eps, s));
-    }
+    if (R > 0) CHECK(uvit_ln_fwd_gather_launch(x_mid, e->rowidx, e->count, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, R, C, e->cfg.ln_eps, s));
     else if (lm) CHECK(uvit_ln_fwd_keep_launch(x_mid, dm.pos, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, x_out, M, C, e->N, e->cfg.ln_eps, s));
     else CHECK(uvit_ln_fwd_launch(x_mid, w.f + o.n2w, w.f + o.n2b, a.ln2, a.mean2, a.rstd2, Mall, C, e->cfg.ln_eps, s));
     GemmEpi f1; f1.out = a.a; f1.out2 = save ? a.h : nullptr; f1.bias = w.f + o.fc1b; f1.ldo = Hd; f1.tile_counter = tcnt;
@@ -671,7 +666,7 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         else if (lm2) { f2.rowmap = d2[st].rows; f2.rowcount = d2[st].cnt; }
         const int M2 = R > 0 ? R : (lm ? Mm : (lm2 ? d2[st].K * e->N : M));
         const bool pf2 = prof_begin(UVIT_PROF_FC2, M2);
-        CHECK(GEMM_NT(EPI_RESID, a.a + ((lm2 || R > 0) ? off2[st] : st * Mp) * Hd, w.b + o.fc2w, M2, C, Hd, Hd, Hd, &f2, s));
+        CHECK(GEMM_NT(EPI_RESID, a.a + (lm2 ? off2[st] : st * Mp) * Hd, w.b + o.fc2w, M2, C, Hd, Hd, Hd, &f2, s));
         prof_end(pf2);
     }
     return UVIT_OK;
@@ -856,7 +851,7 @@ extern "C" int uvit_step_begin(uvit_engine* e, const float* images, const int64_
     e->slab_started = false; e->ls_prefused = -1;
     // the last block's MLP on the masked rows only (see forward_layer): base model, a row bound from the host, and fewer rows than tokens
     e->compact_R = 0;
-    if (hp->n_rows_hint > 0) {      // (two-stream model, end of round 4: the R rows of each stream, stacked, in front of the shared fc1 / fc2)
+    if (e->S == 1 && hp->n_rows_hint > 0) {
         const int R = (int)roundup((size_t)(hp->n_rows_hint < BP ? hp->n_rows_hint : BP), 64);
         if (R >= 512 && R < e->M) {
             e->compact_R = R;
@@ -954,9 +949,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     const int Ma = la ? da.K * e->N : M, Mac = la ? (int)roundup(Ma, 64) : Mred1;
     // two-stream model: the MLP branch on the kept rows of both streams, stacked without a gap (see forward_layer)
     DpList dl2[2] = {}, dl21[2] = {};
-    const bool lm2 = R == 0 && dp_list2(e, l, dl2), lm21 = l > 0 && dp_list2(e, l - 1, dl21);
-    const size_t off2[2] = {0, lm2 ? (size_t)dl2[0].K * e->N : (R > 0 ? (size_t)R : Mp)}, off21[2] = {0, lm21 ? (size_t)dl21[0].K * e->N : Mp};
-    const int Mmlp = R > 0 ? S * R : (lm ? (int)roundup((size_t)dm.K * e->N, 64) : (lm2 ? (int)roundup((size_t)(dl2[0].K + dl2[1].K) * e->N, 64) : Mall));
+    const bool lm2 = dp_list2(e, l, dl2), lm21 = l > 0 && dp_list2(e, l - 1, dl21);
+    const size_t off2[2] = {0, lm2 ? (size_t)dl2[0].K * e->N : Mp}, off21[2] = {0, lm21 ? (size_t)dl21[0].K * e->N : Mp};
+    const int Mmlp = R > 0 ? R : (lm ? (int)roundup((size_t)dm.K * e->N, 64) : (lm2 ? (int)roundup((size_t)(dl2[0].K + dl2[1].K) * e->N, 64) : Mall));
     const int Mmlp_red = (R > 0 || lm || lm2) ? Mmlp : Mred;
     // weight gradients: one grouped launch per layer (bias column sums of fc1 / q / v fused) when every Linear has
     // 256-multiple dimensions; otherwise one launch per Linear as the operands become available
@@ -981,10 +976,9 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     // (the LayerScale backward of a branch rides in the LayerNorm backward that produces its input; in the two-stream
     //  model that kernel is launched once per stream, because drop-path scales and the proj bias differ per stream)
     const bool fuse_ls = true;
-    if (R > 0)       // compact dY1 from the residual-stream gradient and the saved branch output at the listed rows (two-stream: stacked)
-        for (int st = 0; st < S; ++st)
-            CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + off2[st] * C,
-                                     RP(o.g2), RP(o.fc2b), R, C, e->N, NREP, e->n_nd, s, e->rowidx, e->count));
+    if (R > 0)       // compact dY1 from the residual-stream gradient and the saved branch output at the listed rows (S == 1)
+        CHECK(uvit_ls_bwd_launch(e->dXa, a.mlpout, pf + o.g2, dp_ptr(e, dp_on, l, 0, 1, e->B), dY1, RP(o.g2), RP(o.fc2b), R, C, e->N, NREP,
+                                 e->n_nd, s, e->rowidx, e->count));
     else if (e->ls_prefused != l && lm2)   // two-stream: compact dY1 of each stream's kept samples, stacked; the second launch zero-fills the pad rows
         for (int st = 0; st < 2; ++st)
             CHECK(uvit_ls_bwd_launch(e->dXa + st * Mp * C, a.mlpout + st * Mp * C, pf + o.g2, dp_ptr(e, dp_on, l, st, 1, e->B), dY1 + off2[st] * C,
@@ -1029,8 +1023,7 @@ extern "C" int uvit_step_backward_layer(uvit_engine* e, int l, const uvit_step_p
     } else if (fuse_ls) {
         for (int st = 0; st < S; ++st) {
             const size_t ro = st * Mp, eo = ro * C;
-            const size_t cro = R > 0 ? off2[st] : ro;        // the LayerNorm's own rows: compact and stacked in the masked-row last block
-            CHECK(uvit_ln_bwd_ls_launch(e->dLN + cro * C, e->XM[l] + eo, a.mean2 + cro, a.rstd2 + cro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
+            CHECK(uvit_ln_bwd_ls_launch(e->dLN + eo, e->XM[l] + eo, a.mean2 + ro, a.rstd2 + ro, pf + o.n2w, e->dXa + eo, e->dXb + eo,
                                         RP(o.n2w), RP(o.n2b), a.projout + eo, pf + o.g1, dp_ptr(e, dp_on, l, st, 0, e->B), dY2 + eo,
                                         RP(o.g1), RP(off_projb(o, st)), e->N, R > 0 ? R : M, C, NREP, e->n_nd, s,
                                         R > 0 ? e->rowidx : nullptr, R > 0 ? e->count : nullptr,
