@@ -341,7 +341,7 @@ def main():
         check(L.uvit_engine_set_streams(engine.h, engine.stream_mode), "set_streams")
     # the step without the masked-row bound (every row through the last block's MLP): img/s beside `value`, same run
     all_rows_value = None
-    if world == 1 and feed["mask_rows"] and not stochastic and not a.no_alone and not a.single_stream:      # (profiling runs pass --single-stream / --no-alone: timed steps only)
+    if world == 1 and feed["mask_rows"] and not a.no_alone and not a.single_stream:      # (two-stream model: the row bound is ignored, the sample lists are not)      # (profiling runs pass --single-stream / --no-alone: timed steps only)
         keep = feed["mask_rows"]
         feed["mask_rows"] = 0
         keep_dp = engine.drop_path_rows
@@ -377,13 +377,17 @@ def main():
         # layer l (rates linspace(0, 0.25, depth)); per token the attention branch is 8 C^2 (QKV, proj) + 4 N C (core), the MLP 16 C^2, and
         # the student runs them forward + backward (x3; the attention core's backward is 2.5 forwards).  The masked-row last block keeps
         # the dense attention branch and its own row list.
-        dp_lists = bool(engine.drop_path_rows) and not stochastic
+        dp_lists = bool(engine.drop_path_rows)
         skipped_dp = 0.0
         if dp_lists:
             depth_ = model.depth
-            for l_ in range(depth_ - 1 if feed["mask_rows"] else depth_):
+            for l_ in range(depth_):
                 r_ = 0.25 * l_ / (depth_ - 1)
-                skipped_dp += r_ * 197 * (3 * 8 * Cd * Cd + 3.5 * 4 * 197 * Cd + 3 * 16 * Cd * Cd) / 1e9
+                last_masked = bool(feed["mask_rows"]) and not stochastic and l_ == depth_ - 1      # that block's MLP keeps its masked-row list instead
+                if stochastic:                                              # two-stream: the MLP branches only, per stream
+                    skipped_dp += 2 * r_ * 197 * (3 * 16 * Cd * Cd) / 1e9
+                else:
+                    skipped_dp += r_ * 197 * (3 * 8 * Cd * Cd + 3.5 * 4 * 197 * Cd + (0 if last_masked else 3 * 16 * Cd * Cd)) / 1e9
         skipped += skipped_dp
         traffic = pmc_traffic()
         rp = rocprof_avg_us()

@@ -99,10 +99,10 @@ typedef struct uvit_step_params {
      * on the MEAN targets (the covariance targets, :73-86, only know the two layer-norm flags). */
     int32_t target_batch_norm, target_instance_norm, post_target_instance_norm;
     /* Upper bound on the number of masked patches of this batch (the loader has bool_masked_pos on the host before the upload), 0 = not
-     * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the last
+     * given.  The loss reads the student at the masked rows only (modeling_cyclical.py:207,215-225), so with a bound the base model's last
      * block runs its MLP -- forward, dgrads and wgrads -- on those rows alone; results equal the all-rows step.  A bound BELOW the true count
-     * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model runs the R rows of each stream, stacked, through the shared
-     * fc1 / fc2. */
+     * makes the loss NaN (the step is then skipped like any non-finite one); the two-stream model ignores it (measured at the end of round 4:
+     * the per-stream launches and the larger zero fills cost what the skipped rows save). */
     int32_t n_rows_hint;
 } uvit_step_params;
 

@@ -165,8 +165,8 @@ def make_step_params(target_layers, optimizer, max_norm, l1_beta, l2_loss, loss_
                      post_target_layer_norm, cur_decay, do_ema, world, seed, it, train_dropout=True, lambda_pretraining=1e-5,
                      depth=None, target_batch_norm=False, target_instance_norm=False, post_target_instance_norm=False,
                      n_rows_hint=0):
-    """n_rows_hint: an upper bound on the batch's masked patches known on the HOST (0 = unknown): the last block then runs its MLP on
-    those rows only (both models; include/uvit.h, uvit_step_params.n_rows_hint); the results are those of the all-rows step."""
+    """n_rows_hint: an upper bound on the batch's masked patches known on the HOST (0 = unknown): the base model's last block then runs
+    its MLP on those rows only (include/uvit.h, uvit_step_params.n_rows_hint); the results are those of the all-rows step."""
     hp = StepParams()
     if len(target_layers) > MAX_DEPTH:
         raise ValueError(f"at most {MAX_DEPTH} target layers")
