@@ -606,7 +606,8 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
     // counters of the persistent GEMMs' dynamic tile assignment: one block per stream (the teacher and student forwards run side by side)
     static const bool dyn_tiles = !(getenv("UVIT_DYN_TILES") && getenv("UVIT_DYN_TILES")[0] == '0');     // A/B switch
     unsigned* const tcnt = (e->tile_cnt && dyn_tiles) ? e->tile_cnt + ((e->dual && s == e->aux) ? 16 : 0) : nullptr;
-    // drop-path sample lists of the two branches (S == 1, not the masked-row last block): Ma / Mm rows instead of M
+    // drop-path sample lists of the two branches of the base model: Ma / Mm rows instead of M (the masked-row last block keeps its own row list
+    // for the MLP and takes the sample list for the attention branch)
     DpList da{}, dm{};
     const bool la = lists && S == 1 && Bc == e->B && dp_list(e, l, 0, da);     // (also in the masked-row last block: only its MLP keeps the row list)
     const bool lm = lists && R == 0 && S == 1 && Bc == e->B && dp_list(e, l, 1, dm);
@@ -625,7 +626,7 @@ static int forward_layer(uvit_engine* e, const Weights& w, int l, const float* x
         CHECK(uvit_attn2_fwd_launch(a.qkv, a.qkv + Mp * 3 * C, biasP, a.attn, a.attn + Mp * C, a.lse, Bc, e->H, e->N, e->NP, 0.125f,
                                     pdrop, seed, (uint32_t)l, s));
     }
-    // optional HIP-event brackets around the block's full-size forward Linears (bench.py's roofline block)
+    // optional HIP-event brackets around the block's forward Linears, each with the rows of its launch (bench.py's roofline block)
     auto prof_begin = [&](int kind, int rows) -> bool {
         if (!(e->prof_on && e->prof_used + 2 <= e->prof_ev.size())) return false;
         e->prof_kind[e->prof_used / 2] = kind; e->prof_rows[e->prof_used / 2] = rows;
